@@ -1,0 +1,115 @@
+"""fp64 restatement of the reference's lambda-quadrature LPV embedding.
+
+    A(p) = int_0^1 df/dx(lam x, lam u) dlam,   B likewise with df/du,   C with dh/dx
+
+Every rule of the reference is a weighted sum of Jacobians at nodes lam_j p:
+  * lpv_int / lpv_int_C   (lpv_int.py:4-62): composite Simpson, panels [lam_i, lam_i+dlam],
+    lam_0 = 0, lam_{i+1} = lam_i + dlam (accumulated in floating point, lpv_int.py:30),
+    independent `dlam` and `stages`;
+  * lambda_simpson        (lpv_int.py:64-81): the same with dlam = 1/stages;
+  * lambda_trap           (lpv_int.py:83-100): composite trapezoid, weights dlam/2;
+  * par_lpv_int           (par_lpv_int.py:12-33): explicit node vector L laid out as
+    [lam_i]_i, [lam_i+dlam/2]_i, [lam_i+dlam]_i, weights dlam/6 * (1, 4, 1).
+`quad_nodes` returns the node/weight table as written (3*stages nodes for Simpson);
+`merge_nodes` folds bit-identical nodes together (2*stages+1 unique ones).
+"""
+import numpy as np
+
+
+def quad_nodes(rule, stages, dlam=None):
+    """Nodes and weights exactly as the reference enumerates them."""
+    if rule in ("simpson", "trap") and dlam is None:
+        dlam = 1 / stages
+    lam = 0
+    nodes, weights = [], []
+    for _ in range(int(stages)):
+        if rule == "simpson":
+            nodes += [lam, lam + dlam / 2, lam + dlam]
+            weights += [dlam * 1 / 6, 4 * (dlam * 1 / 6), dlam * 1 / 6]
+        elif rule == "trap":
+            nodes += [lam, lam + dlam]
+            weights += [dlam * 1 / 2, dlam * 1 / 2]
+        else:
+            raise ValueError(rule)
+        lam = lam + dlam
+    return np.array(nodes, dtype=np.float64), np.array(weights, dtype=np.float64)
+
+
+def par_nodes(L, dlam, stages):
+    """Node table of par_lpv_int: L = [k1 nodes | k2 nodes | k4 nodes]."""
+    L = np.asarray(L, dtype=np.float64).reshape(-1)
+    assert L.size == 3 * stages
+    w = np.concatenate([np.full(stages, 1.0), np.full(stages, 4.0), np.full(stages, 1.0)]) * (1 / 6 * dlam)
+    return L, w
+
+
+def merge_nodes(nodes, weights):
+    """Sum the weights of bit-identical nodes; keeps first-occurrence order."""
+    out = {}
+    for n, w in zip(nodes.tolist(), weights.tolist()):
+        out[n] = out.get(n, 0.0) + w
+    return np.array(list(out.keys())), np.array(list(out.values()))
+
+
+def embed(model, x, u, nodes, weights, xc=None):
+    """A, B at scheduling points (x,u) and C at points xc, for arrays of points.
+
+    x [..., nx], u [..., nu], xc [..., nx] (defaults to x).  Returns A [..., nx, nx],
+    B [..., nx, nu], C [..., ny, nx].  Summation runs over nodes in table order.
+    """
+    x = np.asarray(x, np.float64); u = np.asarray(u, np.float64)
+    xc = x if xc is None else np.asarray(xc, np.float64)
+    nx = model.nx
+    A = np.zeros(x.shape[:-1] + (nx, nx)); B = np.zeros(x.shape[:-1] + (nx, model.nu))
+    C = np.zeros(xc.shape[:-1] + (model.ny, nx))
+    for lam, w in zip(nodes, weights):
+        J = model.Jf(lam * x, lam * u)
+        A += w * J[..., :, :nx]
+        B += w * J[..., :, nx:]
+        C += w * model.Jhx(lam * xc)
+    return A, B, C
+
+
+# --- reference-named entry points (numeric x, u; Jacobians as callables) ---------------
+def _rule(x, u, Jfx, Jfu, Jhx, nodes, weights):
+    x = np.asarray(x, np.float64); u = np.asarray(u, np.float64)
+    A = B = C = 0.0
+    for lam, w in zip(nodes, weights):
+        A = A + w * np.asarray(Jfx(lam * x, lam * u))
+        B = B + w * np.asarray(Jfu(lam * x, lam * u))
+        if Jhx is not None:
+            C = C + w * np.asarray(Jhx(lam * x, lam * u))
+    return A, B, C
+
+
+def lpv_int(x, nx, u, nu, Jfx, Jfu, dlam, stages):
+    A, B, _ = _rule(x, u, Jfx, Jfu, None, *quad_nodes("simpson", stages, dlam))
+    return A, B
+
+
+def lpv_int_C(x, nx, u, nu, ny, Jfx, Jfu, Jhx, dlam, stages):
+    return _rule(x, u, Jfx, Jfu, Jhx, *quad_nodes("simpson", stages, dlam))
+
+
+def lambda_simpson(x, u, nx, nu, ny, Jfx, Jfu, Jhx, stages):
+    return _rule(x, u, Jfx, Jfu, Jhx, *quad_nodes("simpson", stages))
+
+
+def lambda_trap(x, u, nx, nu, ny, Jfx, Jfu, Jhx, stages):
+    return _rule(x, u, Jfx, Jfu, Jhx, *quad_nodes("trap", stages))
+
+
+def par_lpv_int(x, nx, u, nu, Jfx, Jfu, dlam, stages, L):
+    A, B, _ = _rule(x, u, Jfx, Jfu, None, *par_nodes(L, dlam, stages))
+    return A, B
+
+
+def lpv_rk4(x, u, A, B, dt, correction):
+    """Classic RK4 step of xdot = A x + B u + c with frozen A, B (lpv_rk4.py:1-11); batched."""
+    x = np.asarray(x, np.float64); u = np.asarray(u, np.float64)
+    A = np.asarray(A, np.float64); B = np.asarray(B, np.float64)
+    c = np.asarray(correction, np.float64)
+    bu = np.einsum("...ij,...j->...i", B, u) + c
+    rhs = lambda s: dt * (np.einsum("...ij,...j->...i", A, s) + bu)
+    k1 = rhs(x); k2 = rhs(x + k1 / 2); k3 = rhs(x + k2 / 2); k4 = rhs(x + k3)
+    return x + (k1 + 2 * k2 + 2 * k3 + k4) / 6
