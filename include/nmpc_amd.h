@@ -1,0 +1,89 @@
+/*
+ * nmpc_amd - C ABI of the MI355X (gfx950) implementation of the LPV-NMPC inner loop.
+ *
+ * The reference (Mixxxxx358/NMPC) has no FFI: its hot path is a set of plain Python functions
+ * star-imported into the controller scripts (NMPC.py:10-14).  Each entry point below names the
+ * reference function(s) whose work it performs; the Python package `nmpc_amd` re-exports the
+ * reference's function names on top of these through ctypes.
+ *
+ * Conventions
+ *   - every array argument is CALLER-OWNED DEVICE memory, contiguous, row-major, batch-major,
+ *     unless its comment says "host";
+ *   - fp32 for the network/embedding arrays, fp64 for condensing / QP / controller state;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is
+ *     asynchronous on it; no entry point synchronises the device unless stated;
+ *   - return value 0 = ok, non-zero = error, message via nmpc_last_error() (thread-local);
+ *   - nothing here allocates device memory per call except the *_create functions.
+ */
+#ifndef NMPC_AMD_H
+#define NMPC_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nmpc_model nmpc_model;
+typedef struct nmpc_ctrl nmpc_ctrl;
+
+#define NMPC_MAX_NODES 256
+
+/* quadrature rules of the reference's lpv_int.py / par_lpv_int.py */
+enum { NMPC_RULE_SIMPSON = 0, NMPC_RULE_TRAP = 1 };
+
+const char* nmpc_last_error(void);
+int nmpc_version(void);
+
+/* ---- model: the learned state-space nets (reference: mpcUtil.py:6-82 CasADiExp/Fn/Hn) -------
+ * Each net is  W_lin z + b_lin + W4 tanh(W2 tanh(W0 z + b0) + b2) + b4  with `hidden` units.
+ * params = 8 HOST pointers in the reference's parameter order (mpcUtil.py:18-29):
+ *   [0] W_lin[out,in] [1] b_lin[out] [2] W0[hidden,in] [3] b0 [4] W2[hidden,hidden] [5] b2
+ *   [6] W4[out,hidden] [7] b4.
+ * fn: in = nx+nu, out = nx.  hn: in = nx, out = ny.  enc (observer, may be NULL): in = n_enc_in,
+ * out = nx.  The weights are repacked into device memory owned by the model. */
+int nmpc_model_create(nmpc_model** out, int nx, int nu, int ny, int hidden, int n_enc_in,
+                      const float* const* fn_params, const float* const* hn_params,
+                      const float* const* enc_params);
+void nmpc_model_destroy(nmpc_model* m);
+
+/* ---- LPV embedding (reference: lpv_int.py:4-100 lpv_int / lpv_int_C / lambda_simpson /
+ * lambda_trap, par_lpv_int.py:4-35, mpcUtil.py:136-165 getABlist/getABClist/getClist and the
+ * functorch variant NMPC_test.py:129-201).
+ *   A[p] = sum_j w_j dfdx(lam_j x[p], lam_j u[p]),  B[p] likewise with dfdu,
+ *   C[p] = sum_j w_j dhdx(lam_j xc[p]).
+ * x[npts,nx], u[npts,nu], xc[npts,nx] (device fp32).  A[npts,nx,nx], B[npts,nx,nu], C[npts,ny,nx].
+ * lam/w: HOST arrays of n_nodes <= NMPC_MAX_NODES quadrature nodes and weights.
+ * x,u,A,B may all be NULL (C only); xc,C may both be NULL (A,B only). */
+int nmpc_lpv_embed(const nmpc_model* m, int npts, const float* x, const float* u, const float* xc,
+                   const float* lam, const float* w, int n_nodes, float* A, float* B, float* C,
+                   void* stream);
+
+/* Node table of a rule exactly as the reference enumerates it, bit-identical nodes merged
+ * (lam accumulates by repeated addition of dlam, lpv_int.py:30).  HOST outputs, capacity
+ * NMPC_MAX_NODES each; returns the node count or -1.  dlam <= 0 means 1/stages. */
+int nmpc_quad_nodes(int rule, int stages, double dlam, float* lam, float* w);
+
+/* ---- LPV RK4 predictor (reference: lpv_rk4.py:1-11).  x[n,nx] u[n,nu] A[n,nx,nx] B[n,nx,nu]
+ * c[nx] (device, fp64), xnext[n,nx]. */
+int nmpc_lpv_rk4(int n, int nx, int nu, const double* x, const double* u, const double* A,
+                 const double* B, double dt, const double* c, double* xnext, void* stream);
+
+/* ---- condensed prediction matrices (reference: mpcUtil.py:84-104 getPhi/getGamma,
+ * :322-331 getF0).  list_A[nb,Nc*nx,nx], list_B[nb,Nc*nx,nu], f0[nx] (device fp64).
+ * Phi[nb,Nc*nx,nx], Gamma[nb,Nc*nx,Nc*nu], F0[nb,Nc*nx]; any output may be NULL. */
+int nmpc_condense(int nb, int Nc, int nx, int nu, const double* list_A, const double* list_B,
+                  const double* f0, double* Phi, double* Gamma, double* F0, void* stream);
+
+/* ---- batched dense QP (reference: qpsolvers.solve_qp call sites NMPC_test.py:233,
+ * NMPC.py:458,602,767, mpcUtil.py:224,302):  min 1/2 z'Pz + q'z  s.t. G z <= h, A z = b.
+ * P[nb,n,n] (positive definite), q[nb,n], G[nb,m,n], h[nb,m], Aeq[nb,meq,n], beq[nb,meq]
+ * (device fp64; G/h and Aeq/beq may be NULL with m/meq = 0).  z[nb,n]; lambda[nb,meq+m]
+ * (multipliers, equalities first; may be NULL); status[nb] (0 ok, 1 iteration limit,
+ * 2 infeasible, 3 P not positive definite); iters[nb] (may be NULL). */
+int nmpc_qp_solve(int nb, int n, int m, int meq, const double* P, const double* q, const double* G,
+                  const double* h, const double* Aeq, const double* beq, double* z, double* lambda,
+                  int* status, int* iters, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,5 @@
+"""nmpc_amd: MI355X-native LPV-NMPC inner loop behind the reference's Python call signatures."""
+from ._lib import NmpcError, LIB_PATH  # noqa: F401
+from .model import Encoder, Norm, load_system, DISC_WEIGHTS  # noqa: F401
+from .lpv import (Jacobian, jacobians, quad_nodes, embed, lpv_int, lpv_int_C, lambda_simpson,  # noqa: F401
+                  lambda_trap, par_lpv_int)

@@ -1,0 +1,82 @@
+"""ctypes binding of libnmpc_amd.so (the C ABI declared in include/nmpc_amd.h).
+
+There is no CPU fallback: if the shared library is missing or a call is made without a GPU the
+package raises instead of computing anything on the host.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnmpc_amd.so")
+
+c_float_p = ctypes.POINTER(ctypes.c_float)
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_int_p = ctypes.POINTER(ctypes.c_int)
+c_void_p = ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol include/nmpc_amd.h declares
+SIGNATURES = {
+    "nmpc_last_error": (ctypes.c_char_p, []),
+    "nmpc_version": (ctypes.c_int, []),
+    "nmpc_model_create": (ctypes.c_int, [ctypes.POINTER(c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_float_p),
+                                         ctypes.POINTER(c_float_p), ctypes.POINTER(c_float_p)]),
+    "nmpc_model_destroy": (None, [c_void_p]),
+    "nmpc_lpv_embed": (ctypes.c_int, [c_void_p, ctypes.c_int, c_void_p, c_void_p, c_void_p, c_float_p, c_float_p,
+                                      ctypes.c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nmpc_quad_nodes": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_double, c_float_p, c_float_p]),
+    "nmpc_lpv_rk4": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    ctypes.c_double, c_void_p, c_void_p, c_void_p]),
+    "nmpc_condense": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nmpc_qp_solve": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p]),
+}
+
+_lib = None
+
+
+class NmpcError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the HIP library once; raise loudly if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NmpcError("%s not found: build it with `make -C nmpc_amd/csrc` (hipcc, gfx950); "
+                            "nmpc_amd has no CPU fallback" % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        missing = [name for name in SIGNATURES if not hasattr(handle, name)]
+        if missing:
+            raise NmpcError("%s is stale: it does not export %s; rebuild with `make -C nmpc_amd/csrc`"
+                            % (LIB_PATH, ", ".join(missing)))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise NmpcError("%s failed: %s" % (what, lib().nmpc_last_error().decode()))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise NmpcError("nmpc_amd needs a ROCm GPU (MI355X / gfx950); there is no CPU fallback")

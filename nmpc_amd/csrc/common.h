@@ -1,0 +1,56 @@
+// Shared host/device helpers of the nmpc_amd HIP library.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+namespace nmpc {
+
+void set_error(const char* fmt, ...);
+
+#define NMPC_HIP_CHECK(expr)                                                                  \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            nmpc::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,  \
+                            __LINE__);                                                        \
+            return 1;                                                                         \
+        }                                                                                     \
+    } while (0)
+
+#define NMPC_REQUIRE(cond, ...)                  \
+    do {                                         \
+        if (!(cond)) {                           \
+            nmpc::set_error(__VA_ARGS__);        \
+            return 1;                            \
+        }                                        \
+    } while (0)
+
+constexpr int HID = 64;             // hidden width handled by the MFMA embedding kernel
+// Packed-net layout (float offsets), see pack_net in model.cpp.
+constexpr int PK_WF = 0;          // [4][4][64][4]    forward A-fragments of c2*W2
+constexpr int PK_WR = 4096;       // [4][4][4][64][4] reverse A-fragments of (4 W4[c]) .* W2^T, c = 0..3
+constexpr int PK_REC1 = 20480;    // [64][4] {c2*b0[k], c2*b2[k], 0, 0}
+constexpr int PK_REC2 = 20736;    // [64][4] W0[k][0..3] (zero padded)
+constexpr int PK_LIN = 20992;     // [4][4]  W_lin[c][j] (zero padded)
+constexpr int PACK_FLOATS = 21008;
+constexpr int PK_TAIL = PACK_FLOATS - PK_REC1;   // REC1 + REC2 + LIN, contiguous
+
+// Device-resident packed networks.
+struct ModelDev {
+    int nx, nu, ny, hidden, n_enc_in;
+    float* fpack;   // f-net, MFMA layout
+    float* hpack;   // h-net, MFMA layout
+    float* enc;     // observer net, plain row-major params concatenated (may be null)
+    double f0[16];  // f(0,0)  ("correction",   NMPC_test.py:38)
+    double h0[16];  // h(0)    ("correction_h", NMPC_test.py:41)
+};
+
+}  // namespace nmpc
+
+struct nmpc_model {
+    nmpc::ModelDev d;
+    int device;
+};

@@ -1,0 +1,35 @@
+// Internal interface of the LPV embedding kernel (shared with the controller step).
+#pragma once
+#include "../../include/nmpc_amd.h"
+#include "common.h"
+
+namespace nmpc {
+
+constexpr int EMBED_THREADS = 256;
+constexpr int EMBED_TILE = 16;      // scheduling points per workgroup
+
+struct NodeTable {
+    int n;
+    float lam[NMPC_MAX_NODES];
+    float w[NMPC_MAX_NODES];
+};
+
+struct EmbedArgs {
+    const float* fpack;
+    const float* hpack;
+    const float* x;    // [rows, nx]   scheduling states for A, B
+    const float* u;    // [rows, nu]
+    const float* xc;   // [rows, nx]   scheduling states for C
+    float* A;          // [rows, nx, nx]
+    float* B;          // [rows, nx, nu]
+    float* C;          // [rows, ny, nx]
+    int npts;              // number of points (upper bound when count_dev is set)
+    const int* count_dev;  // optional device word: number of active groups
+    const int* act;        // optional active-group list: point p -> row act[p/group]*group + p%group
+    int group;
+    int n_ftiles;
+};
+
+int embed_launch(const ModelDev& m, EmbedArgs a, const NodeTable& nt, hipStream_t stream);
+
+}  // namespace nmpc

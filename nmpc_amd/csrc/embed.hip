@@ -1,0 +1,258 @@
+// LPV embedding kernel: path-integrated network Jacobians
+//     A[p] = sum_j w_j dfdx(lam_j z_p),  B[p] = sum_j w_j dfdu(lam_j z_p),  C[p] = sum_j w_j dhdx(lam_j x_p)
+// (reference: lpv_int.py:4-100, par_lpv_int.py:4-35, NMPC_test.py:129-201) for nets
+//     net(z) = W_lin z + b_lin + W4 tanh(W2 tanh(W0 z + b0) + b2) + b4,   hidden width 64,
+// whose Jacobian is  W_lin + W4 diag(d2) W2 diag(d1) W0,  d = 1 - tanh^2.
+//
+// Mapping to CDNA4.  One workgroup (4 waves) owns a tile of 16 scheduling points of one net; each
+// wave owns a quarter of the quadrature nodes.  Lane l serves point (l & 15) and the quarter
+// (l >> 4) of the hidden units (16 units per lane keeps the per-lane state near 130 VGPRs).  Per node:
+//   1. layer 1 on the VALU: a1 = lam*(W0 z) + b0 is ONE fma per hidden unit because W0 z does not
+//      depend on lam; tanh through v_exp_f32 / v_rcp_f32 (weights pre-scaled by 2 log2 e);
+//   2. forward product  W2 t1  as 64 v_mfma_f32_16x16x4_f32 with the A fragments of W2 read from
+//      LDS and t1 produced directly in B-fragment layout;
+//   3. d2 from the accumulator in place - the accumulator's row layout is, by construction of
+//      kappa(), the B-fragment layout of the next product, so nothing moves between lanes;
+//   4. reverse products  (W4[c] .* W2)^T d2  (64 MFMAs per output row c);
+//   5. q[c][k] += w * d1[k] * r1[c][k]  - the contraction with W0 is linear and is hoisted out of
+//      the node loop, done once per tile.
+// The four waves' partial sums are combined in LDS in a fixed order (bitwise reproducible).
+#include "../../include/nmpc_amd.h"
+#include "common.h"
+#include "embed.h"
+
+namespace nmpc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// first hidden-unit index of k-step s (lane-quarter hq adds 4*hq): see kappa() in model.cpp
+__device__ __forceinline__ constexpr int kbase(int s) { return 16 * (s >> 2) + (s & 3); }
+
+// e*r and r = 1/(e+1) for e = 2^a, a = c2 * preactivation:  tanh = 1 - 2r,  1 - tanh^2 = 4 (e r) r
+__device__ __forceinline__ void tanh_parts(float a, float& e_r, float& r) {
+    a = __builtin_amdgcn_fmed3f(a, -60.0f, 60.0f);
+    const float e = __builtin_amdgcn_exp2f(a);
+    r = __builtin_amdgcn_rcpf(e + 1.0f);
+    e_r = e * r;
+}
+
+template <int NA, int NB, int NOUT>
+__device__ __forceinline__ void embed_tile(const float* __restrict__ pack, float* __restrict__ lds,
+                                           const float* __restrict__ pa, const float* __restrict__ pb,
+                                           float* __restrict__ oa, float* __restrict__ ob, int tile, int npts,
+                                           const int* __restrict__ act, int group, const NodeTable& nt) {
+    constexpr int NIN = NA + NB;
+    constexpr int L_WR = 4096, L_REC1 = 4096 + 4096 * NOUT, L_REC2 = L_REC1 + 256, L_LIN = L_REC2 + 256,
+                  L_RED = L_LIN + 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, hq = lane >> 4;
+
+    {   // stage the packed net into LDS: WF + NOUT reverse blocks, then the small tables
+        const f32x4* src = reinterpret_cast<const f32x4*>(pack);
+        f32x4* dst = reinterpret_cast<f32x4*>(lds);
+        for (int i = tid; i < (4096 + 4096 * NOUT) / 4; i += EMBED_THREADS) dst[i] = src[i];
+        const f32x4* src2 = reinterpret_cast<const f32x4*>(pack + PK_REC1);
+        f32x4* dst2 = reinterpret_cast<f32x4*>(lds + L_REC1);
+        for (int i = tid; i < PK_TAIL / 4; i += EMBED_THREADS) dst2[i] = src2[i];
+    }
+    __syncthreads();
+    const f32x4* WF = reinterpret_cast<const f32x4*>(lds);
+    const f32x4* WR = reinterpret_cast<const f32x4*>(lds + L_WR);
+    const f32x4* REC1 = reinterpret_cast<const f32x4*>(lds + L_REC1);
+    const f32x4* REC2 = reinterpret_cast<const f32x4*>(lds + L_REC2);
+
+    const int p = tile * EMBED_TILE + n;
+    const bool valid = p < npts;
+    const int pc = valid ? p : npts - 1;
+    const int row = act ? act[pc / group] * group + pc % group : pc;
+    float z[NIN];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) z[j] = pa[(size_t)row * NA + j];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) z[NA + j] = pb[(size_t)row * NB + j];
+
+    constexpr float C2 = 2.8853900817779268f;   // 2 log2(e)
+    float g[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const f32x4 w0 = REC2[kbase(s) + 4 * hq];
+        float a = w0[0] * z[0];
+#pragma unroll
+        for (int j = 1; j < NIN; ++j) a = fmaf(w0[j], z[j], a);
+        g[s] = C2 * a;
+    }
+    float q[NOUT][16];
+#pragma unroll
+    for (int c = 0; c < NOUT; ++c)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) q[c][s] = 0.0f;
+
+    const int nn = nt.n;
+    const int n0 = (nn * wave) >> 2, n1 = (nn * (wave + 1)) >> 2;
+    for (int node = n0; node < n1; ++node) {
+        const float lam = nt.lam[node];
+        const float w4 = 4.0f * nt.w[node];
+        // Re-derive the LDS offsets from opaque values each node: the tables are loop invariant
+        // and would otherwise be hoisted into ~250 registers and spilled.
+        int lo = lane, ho = 4 * hq;
+        asm volatile("" : "+v"(lo), "+v"(ho));
+        float t1[16], wd1[16];
+        f32x4 acc[4];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const f32x4 r1 = REC1[kbase(s) + ho];
+            float er, r;
+            tanh_parts(fmaf(lam, g[s], r1[0]), er, r);
+            t1[s] = fmaf(-2.0f, r, 1.0f);
+            wd1[s] = (w4 * er) * r;               // w * (1 - t1^2)
+            acc[s >> 2][s & 3] = r1[1];
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            f32x4 a[4];
+#pragma unroll
+            for (int T = 0; T < 4; ++T) a[T] = WF[(T * 4 + s4) * 64 + lo];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int T = 0; T < 4; ++T)
+                    acc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[T][j], t1[4 * s4 + j], acc[T], 0, 0, 0);
+        }
+        float d2q[16];                             // (1 - t2^2) / 4
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            float er, r;
+            tanh_parts(acc[s >> 2][s & 3], er, r);
+            d2q[s] = er * r;
+        }
+#pragma unroll
+        for (int c = 0; c < NOUT; ++c) {
+            f32x4 rv[4];
+#pragma unroll
+            for (int T = 0; T < 4; ++T) rv[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                f32x4 a[4];
+#pragma unroll
+                for (int T = 0; T < 4; ++T) a[T] = WR[c * 1024 + (T * 4 + s4) * 64 + lo];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int T = 0; T < 4; ++T)
+                        rv[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[T][j], d2q[4 * s4 + j], rv[T], 0, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) q[c][s] = fmaf(rv[s >> 2][s & 3], wd1[s], q[c][s]);
+        }
+    }
+
+    // contraction with W0 (once per tile), then lane quarters -> one lane, waves -> LDS
+    float pj[NOUT][NIN];
+#pragma unroll
+    for (int c = 0; c < NOUT; ++c)
+#pragma unroll
+        for (int j = 0; j < NIN; ++j) pj[c][j] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const f32x4 w0 = REC2[kbase(s) + 4 * hq];
+#pragma unroll
+        for (int c = 0; c < NOUT; ++c)
+#pragma unroll
+            for (int j = 0; j < NIN; ++j) pj[c][j] = fmaf(q[c][s], w0[j], pj[c][j]);
+    }
+    float* red = lds + L_RED;
+#pragma unroll
+    for (int c = 0; c < NOUT; ++c)
+#pragma unroll
+        for (int j = 0; j < NIN; ++j) {
+            float v = pj[c][j];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (hq == 0) red[(wave * EMBED_TILE + n) * (NOUT * NIN) + c * NIN + j] = v;
+        }
+    __syncthreads();
+    if (tid < EMBED_TILE && valid) {
+        float sumw = 0.0f;
+        for (int i = 0; i < nn; ++i) sumw += nt.w[i];
+        const float* lin = lds + L_LIN;
+#pragma unroll
+        for (int c = 0; c < NOUT; ++c)
+#pragma unroll
+            for (int j = 0; j < NIN; ++j) {
+                float v = red[(0 * EMBED_TILE + n) * (NOUT * NIN) + c * NIN + j];
+#pragma unroll
+                for (int wv = 1; wv < 4; ++wv) v += red[(wv * EMBED_TILE + n) * (NOUT * NIN) + c * NIN + j];
+                v = fmaf(sumw, lin[4 * c + j], v);
+                if (j < NA) oa[((size_t)row * NOUT + c) * NA + j] = v;
+                else ob[((size_t)row * NOUT + c) * NB + (j - NA)] = v;
+            }
+    }
+}
+
+template <int NX, int NU, int NY>
+__global__ __launch_bounds__(EMBED_THREADS, 2) void embed_kernel(EmbedArgs a, NodeTable nt) {
+    extern __shared__ __align__(16) float lds[];
+    int npts = a.npts;
+    if (a.count_dev) npts = min(npts, *a.count_dev * a.group);
+    const int b = blockIdx.x;
+    if (b < a.n_ftiles) {
+        if (b * EMBED_TILE >= npts) return;
+        embed_tile<NX, NU, NX>(a.fpack, lds, a.x, a.u, a.A, a.B, b, npts, a.act, a.group, nt);
+    } else {
+        const int t = b - a.n_ftiles;
+        if (t * EMBED_TILE >= npts) return;
+        embed_tile<NX, 0, NY>(a.hpack, lds, a.xc, nullptr, a.C, nullptr, t, npts, a.act, a.group, nt);
+    }
+}
+
+int embed_launch(const ModelDev& m, EmbedArgs a, const NodeTable& nt, hipStream_t stream) {
+    NMPC_REQUIRE(nt.n >= 1 && nt.n <= NMPC_MAX_NODES, "embed: node count %d out of range", nt.n);
+    NMPC_REQUIRE(a.npts >= 0, "embed: negative point count");
+    if (a.npts == 0) return 0;
+    const bool do_f = a.x && a.u && a.A && a.B, do_h = a.xc && a.C;
+    NMPC_REQUIRE(do_f || do_h, "embed: nothing to compute (need x,u,A,B and/or xc,C)");
+    const int tiles = (a.npts + EMBED_TILE - 1) / EMBED_TILE;
+    a.fpack = m.fpack; a.hpack = m.hpack;
+    a.n_ftiles = do_f ? tiles : 0;
+    if (a.group < 1) a.group = 1;
+    const int grid = a.n_ftiles + (do_h ? tiles : 0);
+    const int nout_max = m.nx > m.ny ? m.nx : m.ny;
+    const size_t lds_bytes = sizeof(float) * (4096 + 4096 * nout_max + PK_TAIL + 4 * EMBED_TILE * 16);
+#define NMPC_EMBED_CASE(NX_, NU_, NY_)                                                            \
+    if (m.nx == NX_ && m.nu == NU_ && m.ny == NY_) {                                              \
+        static bool attr_set = false;                                                             \
+        if (!attr_set) {                                                                          \
+            NMPC_HIP_CHECK(hipFuncSetAttribute((const void*)embed_kernel<NX_, NU_, NY_>,          \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            attr_set = true;                                                                      \
+        }                                                                                         \
+        hipLaunchKernelGGL((embed_kernel<NX_, NU_, NY_>), dim3(grid), dim3(EMBED_THREADS), lds_bytes, stream, a, nt); \
+        NMPC_HIP_CHECK(hipGetLastError());                                                        \
+        return 0;                                                                                 \
+    }
+    NMPC_EMBED_CASE(2, 1, 1)
+    NMPC_EMBED_CASE(3, 1, 1)
+    NMPC_EMBED_CASE(2, 2, 1)
+#undef NMPC_EMBED_CASE
+    set_error("embed: no kernel instantiated for nx=%d nu=%d ny=%d", m.nx, m.nu, m.ny);
+    return 1;
+}
+
+}  // namespace nmpc
+
+using namespace nmpc;
+
+extern "C" int nmpc_lpv_embed(const nmpc_model* m, int npts, const float* x, const float* u, const float* xc,
+                              const float* lam, const float* w, int n_nodes, float* A, float* B, float* C,
+                              void* stream) {
+    NMPC_REQUIRE(m && lam && w, "nmpc_lpv_embed: null argument");
+    NMPC_REQUIRE(n_nodes >= 1 && n_nodes <= NMPC_MAX_NODES, "nmpc_lpv_embed: n_nodes=%d out of [1,%d]", n_nodes,
+                 NMPC_MAX_NODES);
+    NodeTable nt;
+    nt.n = n_nodes;
+    for (int i = 0; i < NMPC_MAX_NODES; ++i) { nt.lam[i] = i < n_nodes ? lam[i] : 0.f; nt.w[i] = i < n_nodes ? w[i] : 0.f; }
+    EmbedArgs a{};
+    a.x = x; a.u = u; a.xc = xc; a.A = A; a.B = B; a.C = C; a.npts = npts; a.group = 1;
+    return embed_launch(m->d, a, nt, (hipStream_t)stream);
+}

@@ -1,0 +1,140 @@
+// Model handle: repacks the reference-ordered network parameters into the layouts the kernels
+// read, and evaluates the constant offsets f(0,0), h(0) (NMPC_test.py:38-43) in fp64.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/nmpc_amd.h"
+#include "common.h"
+
+namespace nmpc {
+
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+// Hidden-unit index supplied by lane-quarter hq at MFMA k-step s (v_mfma_f32_16x16x4_f32).  It
+// equals the row that register (s & 3) of output tile (s >> 2) of a 16x16 f32 accumulator holds in
+// lane-quarter hq, so an accumulator can be fed straight back as the B operand of the next product.
+static inline int kappa(int s, int hq) { return 16 * (s >> 2) + 4 * hq + (s & 3); }
+
+static void pack_net(const float* const* p, int n_in, int n_out, std::vector<float>& out) {
+    const float *lin_w = p[0], *w0 = p[2], *b0 = p[3], *w2 = p[4], *b2 = p[5], *w4 = p[6];
+    const double c2 = 2.0 * 1.4426950408889634074;  // tanh(a) = 1 - 2/(2^(c2 a) + 1)
+    out.assign(PACK_FLOATS, 0.0f);
+    for (int T = 0; T < 4; ++T)
+        for (int s = 0; s < 16; ++s)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int hq = lane >> 4, r = lane & 15, k = kappa(s, hq);
+                const size_t o = ((size_t)(T * 4 + (s >> 2)) * 64 + lane) * 4 + (s & 3);
+                out[PK_WF + o] = (float)(c2 * (double)w2[(16 * T + r) * HID + k]);
+                // reverse product r1[kk] = sum_i W2[i][kk] * (4 W4[c][i]) * (d2[i]/4); reduction index i = k
+                for (int c = 0; c < n_out; ++c)
+                    out[PK_WR + 4096 * c + o] = (float)((double)w2[k * HID + 16 * T + r] * 4.0 * (double)w4[c * HID + k]);
+            }
+    for (int k = 0; k < HID; ++k) {
+        out[PK_REC1 + 4 * k + 0] = (float)(c2 * (double)b0[k]);
+        out[PK_REC1 + 4 * k + 1] = (float)(c2 * (double)b2[k]);
+        for (int j = 0; j < n_in; ++j) out[PK_REC2 + 4 * k + j] = w0[k * n_in + j];
+    }
+    for (int c = 0; c < n_out; ++c)
+        for (int j = 0; j < n_in; ++j) out[PK_LIN + 4 * c + j] = lin_w[c * n_in + j];
+}
+
+static void eval_net_at_zero(const float* const* p, int n_in, int n_out, int hidden, double* y) {
+    std::vector<double> t1(hidden), t2(hidden);
+    for (int k = 0; k < hidden; ++k) t1[k] = std::tanh((double)p[3][k]);
+    for (int i = 0; i < hidden; ++i) {
+        double a = p[5][i];
+        for (int k = 0; k < hidden; ++k) a += (double)p[4][i * hidden + k] * t1[k];
+        t2[i] = std::tanh(a);
+    }
+    for (int c = 0; c < n_out; ++c) {
+        double a = (double)p[1][c] + (double)p[7][c];
+        for (int k = 0; k < hidden; ++k) a += (double)p[6][c * hidden + k] * t2[k];
+        y[c] = a;
+    }
+    (void)n_in;
+}
+
+}  // namespace nmpc
+
+using namespace nmpc;
+
+extern "C" const char* nmpc_last_error(void) { return g_err.c_str(); }
+extern "C" int nmpc_version(void) { return 100; }
+
+extern "C" int nmpc_model_create(nmpc_model** out, int nx, int nu, int ny, int hidden, int n_enc_in,
+                                 const float* const* fn, const float* const* hn,
+                                 const float* const* enc) {
+    NMPC_REQUIRE(out && fn && hn, "nmpc_model_create: null argument");
+    NMPC_REQUIRE(hidden == HID, "nmpc_model_create: hidden width %d unsupported (kernel is built for %d)",
+                 hidden, HID);
+    NMPC_REQUIRE(nx >= 1 && nu >= 1 && ny >= 1 && nx + nu <= 4 && nx <= 4 && ny <= 4,
+                 "nmpc_model_create: dims nx=%d nu=%d ny=%d unsupported (need nx+nu<=4, ny<=4)", nx, nu, ny);
+    NMPC_REQUIRE(!enc || (n_enc_in >= 1 && n_enc_in <= 32), "nmpc_model_create: bad encoder input size %d",
+                 n_enc_in);
+    nmpc_model* m = new nmpc_model();
+    std::memset(m, 0, sizeof(*m));
+    m->d.nx = nx; m->d.nu = nu; m->d.ny = ny; m->d.hidden = hidden; m->d.n_enc_in = enc ? n_enc_in : 0;
+    NMPC_HIP_CHECK(hipGetDevice(&m->device));
+    std::vector<float> buf;
+    pack_net(fn, nx + nu, nx, buf);
+    NMPC_HIP_CHECK(hipMalloc(&m->d.fpack, PACK_FLOATS * sizeof(float)));
+    NMPC_HIP_CHECK(hipMemcpy(m->d.fpack, buf.data(), PACK_FLOATS * sizeof(float), hipMemcpyHostToDevice));
+    pack_net(hn, nx, ny, buf);
+    NMPC_HIP_CHECK(hipMalloc(&m->d.hpack, PACK_FLOATS * sizeof(float)));
+    NMPC_HIP_CHECK(hipMemcpy(m->d.hpack, buf.data(), PACK_FLOATS * sizeof(float), hipMemcpyHostToDevice));
+    eval_net_at_zero(fn, nx + nu, nx, hidden, m->d.f0);
+    eval_net_at_zero(hn, nx, ny, hidden, m->d.h0);
+    if (enc) {
+        // plain concatenation: lin_w[nx,in] lin_b[nx] w0[H,in] b0[H] w2[H,H] b2[H] w4[nx,H] b4[nx]
+        const int sz[8] = {nx * n_enc_in, nx, hidden * n_enc_in, hidden, hidden * hidden, hidden, nx * hidden, nx};
+        std::vector<float> e;
+        for (int i = 0; i < 8; ++i) e.insert(e.end(), enc[i], enc[i] + sz[i]);
+        NMPC_HIP_CHECK(hipMalloc(&m->d.enc, e.size() * sizeof(float)));
+        NMPC_HIP_CHECK(hipMemcpy(m->d.enc, e.data(), e.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    *out = m;
+    return 0;
+}
+
+extern "C" void nmpc_model_destroy(nmpc_model* m) {
+    if (!m) return;
+    if (m->d.fpack) (void)hipFree(m->d.fpack);
+    if (m->d.hpack) (void)hipFree(m->d.hpack);
+    if (m->d.enc) (void)hipFree(m->d.enc);
+    delete m;
+}
+
+extern "C" int nmpc_quad_nodes(int rule, int stages, double dlam, float* lam_out, float* w_out) {
+    if (stages < 1 || !lam_out || !w_out) { set_error("nmpc_quad_nodes: bad argument"); return -1; }
+    if (dlam <= 0) dlam = 1.0 / stages;
+    std::vector<double> nodes, weights;
+    auto add = [&](double l, double w) {
+        for (size_t i = 0; i < nodes.size(); ++i)
+            if (nodes[i] == l) { weights[i] += w; return; }
+        nodes.push_back(l); weights.push_back(w);
+    };
+    double lam = 0;
+    for (int i = 0; i < stages; ++i) {
+        if (rule == NMPC_RULE_SIMPSON) {
+            const double w = dlam * 1 / 6;
+            add(lam, w); add(lam + dlam / 2, 4 * w); add(lam + dlam, w);
+        } else if (rule == NMPC_RULE_TRAP) {
+            const double w = dlam * 1 / 2;
+            add(lam, w); add(lam + dlam, w);
+        } else { set_error("nmpc_quad_nodes: unknown rule %d", rule); return -1; }
+        lam = lam + dlam;
+    }
+    if (nodes.size() > NMPC_MAX_NODES) { set_error("nmpc_quad_nodes: %zu nodes exceed %d", nodes.size(), NMPC_MAX_NODES); return -1; }
+    for (size_t i = 0; i < nodes.size(); ++i) { lam_out[i] = (float)nodes[i]; w_out[i] = (float)weights[i]; }
+    return (int)nodes.size();
+}

@@ -1,0 +1,110 @@
+"""LPV embedding with the reference's call signatures (lpv_int.py, par_lpv_int.py, lpv_rk4.py and
+mpcUtil.py:136-165), batched: x[..., nx], u[..., nu] are torch tensors on the GPU and every
+leading dimension is a batch of independent scheduling points.
+
+`Jfx`, `Jfu`, `Jhx` are model-bound handles (the reference passes CasADi Jacobian functions of
+the same nets); the quadrature and the Jacobians are evaluated together by one HIP kernel, so
+the handles only carry the model."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check, ptr, current_stream
+
+
+class Jacobian:
+    """Handle standing for the reference's CasADi Function Jfx / Jfu / Jhx (NMPC_test.py:53-55)."""
+
+    def __init__(self, model, kind):
+        assert kind in ("fx", "fu", "hx")
+        self.model, self.kind = model, kind
+
+
+def jacobians(model):
+    return Jacobian(model, "fx"), Jacobian(model, "fu"), Jacobian(model, "hx")
+
+
+def quad_nodes(rule, stages, dlam=None):
+    """Merged node table of a rule as fp32 host arrays (nmpc_quad_nodes)."""
+    lam = np.zeros(256, np.float32); w = np.zeros(256, np.float32)
+    code = {"simpson": 0, "trap": 1}[rule]
+    n = lib().nmpc_quad_nodes(code, int(stages), float(dlam) if dlam else 0.0,
+                              lam.ctypes.data_as(_lib.c_float_p), w.ctypes.data_as(_lib.c_float_p))
+    if n < 0:
+        raise _lib.NmpcError(lib().nmpc_last_error().decode())
+    return lam[:n].copy(), w[:n].copy()
+
+
+def _merge(nodes, weights):
+    out = {}
+    for n, w in zip(np.asarray(nodes, np.float64).tolist(), np.asarray(weights, np.float64).tolist()):
+        out[n] = out.get(n, 0.0) + w
+    return np.array(list(out.keys()), np.float32), np.array(list(out.values()), np.float32)
+
+
+def _f32(t, model, last):
+    t = torch.as_tensor(t, device=model.device)
+    if t.dtype != torch.float32:
+        t = t.to(torch.float32)
+    if t.dim() == 0:
+        t = t.reshape(1)
+    assert t.shape[-1] == last, "last dimension must be %d, got %s" % (last, tuple(t.shape))
+    return t.contiguous()
+
+
+def embed(model, x=None, u=None, xc=None, lam=None, w=None):
+    """A, B at (x, u) and/or C at xc for arbitrary leading batch dims; returns (A, B, C) with
+    None for the parts not requested."""
+    lam = np.ascontiguousarray(lam, np.float32); w = np.ascontiguousarray(w, np.float32)
+    A = B = C = None
+    npts = None
+    if x is not None:
+        x = _f32(x, model, model.nx); u = _f32(u, model, model.nu)
+        u = u.expand(x.shape[:-1] + (model.nu,)).contiguous() if u.shape[:-1] != x.shape[:-1] else u
+        npts = x.numel() // model.nx
+        A = torch.empty(x.shape[:-1] + (model.nx, model.nx), device=model.device, dtype=torch.float32)
+        B = torch.empty(x.shape[:-1] + (model.nx, model.nu), device=model.device, dtype=torch.float32)
+    if xc is not None:
+        xc = _f32(xc, model, model.nx)
+        nc = xc.numel() // model.nx
+        assert npts is None or nc == npts, "x and xc must hold the same number of points"
+        npts = nc
+        C = torch.empty(xc.shape[:-1] + (model.ny, model.nx), device=model.device, dtype=torch.float32)
+    with torch.cuda.device(model.device):
+        rc = lib().nmpc_lpv_embed(model.handle, npts, ptr(x), ptr(u), ptr(xc),
+                                  lam.ctypes.data_as(_lib.c_float_p), w.ctypes.data_as(_lib.c_float_p), lam.size,
+                                  ptr(A), ptr(B), ptr(C), current_stream())
+    check(rc, "nmpc_lpv_embed")
+    return A, B, C
+
+
+def lpv_int(x, nx, u, nu, Jfx, Jfu, dlam, stages):
+    """lpv_int.py:4-32."""
+    A, B, _ = embed(Jfx.model, x, u, None, *quad_nodes("simpson", stages, dlam))
+    return A, B
+
+
+def lpv_int_C(x, nx, u, nu, ny, Jfx, Jfu, Jhx, dlam, stages):
+    """lpv_int.py:34-62 (C is evaluated at the same x)."""
+    return embed(Jfx.model, x, u, x, *quad_nodes("simpson", stages, dlam))
+
+
+def lambda_simpson(x, u, nx, nu, ny, Jfx, Jfu, Jhx, stages):
+    """lpv_int.py:64-81."""
+    return embed(Jfx.model, x, u, x, *quad_nodes("simpson", stages))
+
+
+def lambda_trap(x, u, nx, nu, ny, Jfx, Jfu, Jhx, stages):
+    """lpv_int.py:83-100."""
+    return embed(Jfx.model, x, u, x, *quad_nodes("trap", stages))
+
+
+def par_lpv_int(x, nx, u, nu, Jfx, Jfu, dlam, stages, L):
+    """par_lpv_int.py:4-35: explicit node vector L = [k1 nodes | k2 nodes | k4 nodes]."""
+    L = np.asarray(L, np.float64).reshape(-1)
+    assert L.size == 3 * stages
+    wts = np.concatenate([np.full(stages, 1.0), np.full(stages, 4.0), np.full(stages, 1.0)]) * (1 / 6 * dlam)
+    A, B, _ = embed(Jfx.model, x, u, None, *_merge(L, wts))
+    return A, B

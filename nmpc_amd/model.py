@@ -1,0 +1,73 @@
+"""Host-side handle of the learned state-space model (the reference's `I_enc`, a deepSI
+SS_encoder_general): attributes the controllers read (nx, nu, ny, na, nb, norm.{u0,ustd,y0,ystd})
+plus the device-resident packed networks."""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _lib
+
+_NAMES = ("lin_w", "lin_b", "w0", "b0", "w2", "b2", "w4", "b4")
+DISC_WEIGHTS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "disc_snr30.npz")
+
+
+class Norm:
+    """deepSI System_data_norm: u_norm = (u - u0)/ustd, y_norm = (y - y0)/ystd."""
+
+    def __init__(self, u0=0.0, ustd=1.0, y0=0.0, ystd=1.0):
+        self.u0, self.ustd, self.y0, self.ystd = float(u0), float(ustd), float(y0), float(ystd)
+
+
+class Encoder:
+    """fn / hn / encoder nets on the device.  `params` maps net name -> 8 fp32 arrays in the
+    reference's parameter order (mpcUtil.py:18-29)."""
+
+    def __init__(self, params, norm=None, na=4, nb=4, device=None):
+        import torch
+        _lib.require_gpu()
+        self.params = {k: [np.ascontiguousarray(a, dtype=np.float32) for a in v] for k, v in params.items()}
+        fn, hn = self.params["fn"], self.params["hn"]
+        self.hidden = fn[2].shape[0]
+        self.nx = hn[2].shape[1]
+        self.nu = fn[2].shape[1] - self.nx
+        self.ny = hn[6].shape[0]
+        self.na, self.nb = int(na), int(nb)
+        self.norm = norm or Norm()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        enc = self.params.get("enc")
+        self.n_enc_in = enc[2].shape[1] if enc is not None else 0
+
+        def parr(lst):
+            arr = (_lib.c_float_p * 8)()
+            for i, a in enumerate(lst):
+                arr[i] = a.ctypes.data_as(_lib.c_float_p)
+            return arr
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = _lib.lib().nmpc_model_create(ctypes.byref(h), self.nx, self.nu, self.ny, self.hidden, self.n_enc_in,
+                                              parr(fn), parr(hn), parr(enc) if enc is not None else None)
+        _lib.check(rc, "nmpc_model_create")
+        self.handle = h
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h:
+            try:
+                _lib.lib().nmpc_model_destroy(h)
+            except Exception:
+                pass
+            self.handle = None
+
+    @classmethod
+    def from_npz(cls, path=DISC_WEIGHTS, device=None):
+        d = np.load(path)
+        params = {net: [d["%s_%s" % (net, n)] for n in _NAMES] for net in ("fn", "hn", "enc")
+                  if "%s_w0" % net in d}
+        norm = Norm(d["u0"], d["ustd"], d["y0"], d["ystd"]) if "u0" in d else Norm()
+        return cls(params, norm, int(d["na"]) if "na" in d else 4, int(d["nb"]) if "nb" in d else 4, device)
+
+
+def load_system(path=DISC_WEIGHTS, device=None):
+    """Counterpart of deepSI.load_system (NMPC_test.py:362) for weight files in .npz form."""
+    return Encoder.from_npz(path, device)
