@@ -1,0 +1,308 @@
+// Dual active-set (Goldfarb-Idnani) solver for small strictly convex QPs, one problem per lane
+// GROUP (GS = 16, 32 or 64 lanes of one wavefront), all data in LDS, fp64.
+//
+//     min 1/2 z'Pz + q'z   s.t.  a_i'z = b_i (i < meq),   g_i'z <= h_i
+//
+// (reference: the qpsolvers.solve_qp call sites NMPC_test.py:233, NMPC.py:458,602,767,
+// mpcUtil.py:224,302; "quadprog", NMPC.py:458, is this algorithm.)
+//
+// Formulation.  With P = L L', constraint normals n_i = -g_i and the change of variables
+// zt = L'z the Hessian becomes the identity, constraint i reads  s_i = h_i + nt_i . zt >= 0  with
+// nt_i = L^-1 n_i, and the whole iteration runs on the n x mt matrix Nt = [nt_i]:
+//   - the working-set Gram matrix K_WW = Nt_W' Nt_W is kept as its Cholesky factor Lw; adding
+//     constraint p appends the row [l, delta] with l = Lw^-1 Nt_W' nt_p, delta^2 = |nt_p|^2 - |l|^2
+//     (delta^2 is also the curvature of the primal step), dropping one rebuilds Lw;
+//   - dual direction r = Lw^-T l, primal direction v = nt_p - Nt_W r (in zt coordinates);
+//   - every lane owns constraints i = gl, gl+GS, ... and updates their slacks s_i += t nt_i . v,
+//     so the "most violated constraint" search is a group reduction over registers.
+// The primal point is recovered once at the end from the multipliers:  L' z = zt_unc + Nt_W lam.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace nmpc {
+
+constexpr double QP_INF = 1e300;
+
+template <int GS>
+__device__ __forceinline__ double g_bcast(double v, int src_gl) {
+    const int lane = threadIdx.x & 63;
+    return __shfl(v, (lane & ~(GS - 1)) + src_gl, 64);
+}
+template <int GS>
+__device__ __forceinline__ int g_bcast_i(int v, int src_gl) {
+    const int lane = threadIdx.x & 63;
+    return __shfl(v, (lane & ~(GS - 1)) + src_gl, 64);
+}
+template <int GS>
+__device__ __forceinline__ double g_sum(double v) {
+#pragma unroll
+    for (int m = GS / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+// minimum and its index (ties -> smaller index), result identical in every lane of the group
+template <int GS>
+__device__ __forceinline__ void g_argmin(double& v, int& idx) {
+#pragma unroll
+    for (int m = GS / 2; m >= 1; m >>= 1) {
+        const double ov = __shfl_xor(v, m, 64);
+        const int oi = __shfl_xor(idx, m, 64);
+        if (ov < v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+}
+// orders this wave's LDS traffic for the compiler; the hardware executes one wave's DS
+// instructions in order
+__device__ __forceinline__ void g_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// In-place Cholesky of the leading nn x nn block of M (row-major, leading dimension ld), lower
+// factor; invd[j] = 1 / L[j][j].  Returns false if a pivot is not positive.
+template <int GS>
+__device__ __forceinline__ bool g_chol(double* M, int nn, int ld, double* invd, int gl) {
+    for (int j = 0; j < nn; ++j) {
+        const double d = M[j * ld + j];
+        if (!(d > 0.0)) return false;
+        const double inv = 1.0 / sqrt(d);
+        g_sync();
+        for (int i = gl; i < nn; i += GS)
+            if (i >= j) M[i * ld + j] *= inv;
+        if (gl == 0) invd[j] = inv;
+        g_sync();
+        for (int i = gl; i < nn; i += GS)
+            if (i > j) {
+                const double lij = M[i * ld + j];
+                for (int c = j + 1; c <= i; ++c) M[i * ld + c] -= lij * M[c * ld + j];
+            }
+        g_sync();
+    }
+    return true;
+}
+
+// LDS footprint in doubles of one problem (ints of the working set included, rounded up)
+__host__ __device__ inline int qp_lds_doubles(int n, int mt) { return 2 * n * n + n * mt + mt + 8 * n; }
+
+struct QPWork {
+    double *Lm, *Nt, *hv, *xt, *Lw, *vv, *rW, *lamW, *invdL, *invdW, *lam_out;
+    int* Wl;
+    __device__ void carve(double* base, int n, int mt) {
+        Lm = base; Lw = Lm + n * n; Nt = Lw + n * n; hv = Nt + n * mt; xt = hv + mt; vv = xt + n; rW = vv + n;
+        lamW = rW + n; invdL = lamW + n; invdW = invdL + n; lam_out = nullptr;
+        Wl = reinterpret_cast<int*>(invdW + n);   // n ints in the 2n-double tail
+    }
+};
+
+// On entry: Lm = P (full symmetric n x n), Nt[k*mt+i] = coefficient k of constraint row i
+// (equalities first), hv = right-hand sides, xt = q.  On exit: xt = optimum z; if lam != null,
+// lam[i] = multiplier of row i.  Requires n <= GS and mt <= GS*MPL.
+// Returns 0 ok, 1 iteration limit, 2 infeasible, 3 P not positive definite.
+template <int GS, int MPL>
+__device__ int gi_solve(int n, int mt, int meq, QPWork& w, double* lam, int* iters_out) {
+    const int gl = (threadIdx.x & 63) & (GS - 1);
+    double *Lm = w.Lm, *Nt = w.Nt, *hv = w.hv, *xt = w.xt, *Lw = w.Lw;
+    int status = 0, iters = 0;
+    g_sync();
+    if (!g_chol<GS>(Lm, n, n, w.invdL, gl)) {
+        if (iters_out) *iters_out = 0;
+        return 3;
+    }
+    // nt_i = L^-1 (-g_i) for every constraint, zt_unc = -L^-1 q  (one column per lane)
+    for (int i = gl; i <= mt; i += GS) {
+        double* col = i < mt ? Nt + i : xt;
+        const int st = i < mt ? mt : 1;
+        for (int k = 0; k < n; ++k) {
+            double v = -col[k * st];
+            for (int l = 0; l < k; ++l) v -= Lm[k * n + l] * col[l * st];
+            col[k * st] = v * w.invdL[k];
+        }
+    }
+    g_sync();
+    double s[MPL], sgn[MPL];
+    unsigned amask = 0;
+#pragma unroll
+    for (int sl = 0; sl < MPL; ++sl) {
+        const int i = gl + sl * GS;
+        double v = 0.0;
+        if (i < mt) {
+            v = hv[i];
+            for (int k = 0; k < n; ++k) v += Nt[k * mt + i] * xt[k];
+        }
+        s[sl] = v; sgn[sl] = 1.0;
+    }
+    int q = 0, eq_next = 0;
+    double lamj = 0.0;        // multiplier of working-set position gl
+    int wj = -1;              // constraint index at working-set position gl
+    const int max_iter = 10 * (n + mt) + 20;
+    for (;;) {
+        int p; double sp;
+        if (eq_next < meq) {
+            p = eq_next++;
+            double sv = 0.0;
+#pragma unroll
+            for (int sl = 0; sl < MPL; ++sl) if (sl == p / GS) sv = s[sl];
+            sp = g_bcast<GS>(sv, p % GS);
+            if (fabs(sp) <= 1e-12 * (1.0 + fabs(hv[p]))) continue;
+            if (sp > 0.0) {   // flip the row so that it reads as violated
+                g_sync();
+                for (int k = gl; k < n; k += GS) Nt[k * mt + p] = -Nt[k * mt + p];
+                g_sync();
+#pragma unroll
+                for (int sl = 0; sl < MPL; ++sl) if (gl + sl * GS == p) { s[sl] = -s[sl]; sgn[sl] = -1.0; }
+                sp = -sp;
+            }
+        } else {
+            double best = QP_INF; int bi = 0x7fffffff;
+#pragma unroll
+            for (int sl = 0; sl < MPL; ++sl) {
+                const int i = gl + sl * GS;
+                if (i < mt && i >= meq && !(amask >> sl & 1u)) {
+                    const double sc = s[sl] / (1.0 + fabs(hv[i]));
+                    if (sc < best) { best = sc; bi = i; }
+                }
+            }
+            g_argmin<GS>(best, bi);
+            if (!(best < -1e-10)) break;
+            p = bi;
+            double sv = 0.0;
+#pragma unroll
+            for (int sl = 0; sl < MPL; ++sl) if (sl == p / GS) sv = s[sl];
+            sp = g_bcast<GS>(sv, p % GS);
+        }
+        double lam_p = 0.0;
+        for (;;) {
+            if (++iters > max_iter) { status = 1; break; }
+            double kp = 0.0, kpp = 0.0;
+            for (int k = 0; k < n; ++k) {
+                const double np_k = Nt[k * mt + p];
+                kpp += np_k * np_k;
+                if (gl < q) kp += Nt[k * mt + wj] * np_k;
+            }
+            // l = Lw^-1 kp
+            double v = kp, lj = 0.0;
+            for (int i = 0; i < q; ++i) {
+                const double li = g_bcast<GS>(v, i) * w.invdW[i];
+                if (gl == i) lj = li;
+                if (gl > i && gl < q) v -= Lw[gl * n + i] * li;
+            }
+            const double dd = kpp - g_sum<GS>(gl < q ? lj * lj : 0.0);
+            // r = Lw^-T l
+            v = lj;
+            double rj = 0.0;
+            for (int i = q - 1; i >= 0; --i) {
+                const double ri = g_bcast<GS>(v, i) * w.invdW[i];
+                if (gl == i) rj = ri;
+                if (gl < i) v -= Lw[i * n + gl] * ri;
+            }
+            double t1 = QP_INF; int kd = 0x7fffffff;
+            if (gl < q && wj >= meq && rj > 1e-13) { t1 = lamj / rj; kd = gl; }
+            g_argmin<GS>(t1, kd);
+            const bool primal = dd > 1e-12 * kpp && kpp > 0.0;
+            const double t2 = primal ? -sp / dd : QP_INF;
+            const double t = t1 < t2 ? t1 : t2;
+            if (!(t < QP_INF)) { status = 2; break; }
+            if (primal) {
+                g_sync();
+                if (gl < q) { w.rW[gl] = rj; w.Wl[gl] = wj; }
+                g_sync();
+                for (int k = gl; k < n; k += GS) {
+                    double a = Nt[k * mt + p];
+                    for (int j = 0; j < q; ++j) a -= Nt[k * mt + w.Wl[j]] * w.rW[j];
+                    w.vv[k] = a;
+                }
+                g_sync();
+#pragma unroll
+                for (int sl = 0; sl < MPL; ++sl) {
+                    const int i = gl + sl * GS;
+                    if (i < mt) {
+                        double dot = 0.0;
+                        for (int k = 0; k < n; ++k) dot += Nt[k * mt + i] * w.vv[k];
+                        s[sl] += t * dot;
+                    }
+                }
+            }
+            if (gl < q) lamj -= t * rj;
+            lam_p += t;
+            if (primal && t2 <= t1) {          // full step: p joins the working set at position q
+                g_sync();
+                if (gl < q) Lw[q * n + gl] = lj;
+                if (gl == q) {
+                    const double dl = sqrt(dd);
+                    Lw[q * n + q] = dl; w.invdW[q] = 1.0 / dl;
+                    lamj = lam_p; wj = p;
+                }
+                g_sync();
+#pragma unroll
+                for (int sl = 0; sl < MPL; ++sl) if (gl + sl * GS == p) { s[sl] = 0.0; amask |= 1u << sl; }
+                ++q;
+                break;
+            }
+            // partial (or dual-only) step: constraint at position kd leaves the working set
+            {
+                const int dropped = g_bcast_i<GS>(wj, kd);
+#pragma unroll
+                for (int sl = 0; sl < MPL; ++sl) if (gl + sl * GS == dropped) amask &= ~(1u << sl);
+                const double lnext = g_bcast<GS>(lamj, (gl + 1) & (GS - 1));
+                const int wnext = g_bcast_i<GS>(wj, (gl + 1) & (GS - 1));
+                if (gl >= kd && gl < q - 1) { lamj = lnext; wj = wnext; }
+                --q;
+                if (gl >= q) { lamj = 0.0; wj = -1; }
+                // rebuild Lw = chol(Nt_W' Nt_W)
+                g_sync();
+                if (gl < q) w.Wl[gl] = wj;
+                g_sync();
+                if (gl < q)
+                    for (int b = 0; b <= gl; ++b) {
+                        const int wb = w.Wl[b];
+                        double a = 0.0;
+                        for (int k = 0; k < n; ++k) a += Nt[k * mt + wj] * Nt[k * mt + wb];
+                        Lw[gl * n + b] = a;
+                    }
+                g_sync();
+                if (!g_chol<GS>(Lw, q, n, w.invdW, gl)) { status = 2; break; }
+                double sv = 0.0;
+#pragma unroll
+                for (int sl = 0; sl < MPL; ++sl) if (sl == p / GS) sv = s[sl];
+                sp = g_bcast<GS>(sv, p % GS);
+            }
+        }
+        if (status) break;
+    }
+    // z:  L' z = zt_unc + Nt_W lam
+    g_sync();
+    if (gl < q) { w.lamW[gl] = lamj; w.Wl[gl] = wj; }
+    g_sync();
+    for (int k = gl; k < n; k += GS) {
+        double a = xt[k];
+        for (int j = 0; j < q; ++j) a += Nt[k * mt + w.Wl[j]] * w.lamW[j];
+        w.vv[k] = a;
+    }
+    g_sync();
+    {
+        double v = gl < n ? w.vv[gl] : 0.0, xres = 0.0;
+        for (int i = n - 1; i >= 0; --i) {
+            const double xi = g_bcast<GS>(v, i) * w.invdL[i];
+            if (gl == i) xres = xi;
+            if (gl < i) v -= Lm[i * n + gl] * xi;
+        }
+        g_sync();
+        if (gl < n) xt[gl] = xres;
+    }
+    if (lam) {   // a flipped equality row carries its sign with the lane that owns the row
+        g_sync();
+        for (int i = gl; i < mt; i += GS) lam[i] = 0.0;
+        g_sync();
+        if (gl < q) lam[wj] = lamj;
+        g_sync();
+#pragma unroll
+        for (int sl = 0; sl < MPL; ++sl) {
+            const int i = gl + sl * GS;
+            if (i < mt) lam[i] *= sgn[sl];
+        }
+    }
+    g_sync();
+    if (iters_out) *iters_out = iters;
+    return status;
+}
+
+}  // namespace nmpc
