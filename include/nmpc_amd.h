@@ -83,6 +83,56 @@ int nmpc_qp_solve(int nb, int n, int m, int meq, const double* P, const double* 
                   const double* h, const double* Aeq, const double* beq, double* z, double* lambda,
                   int* status, int* iters, void* stream);
 
+/* ---- one condensed MPC QP of the output-constrained controller (reference: NMPC_test.py:206-238):
+ * F0/Phi/Gamma/Z, G = 2(Psi + Gamma' Omega Gamma), F = 2(Gamma' Omega (Phi x0 + F0 - Xs) - Psi Us),
+ * L = M Z Gamma + E with one slack column of -1, h = c - D y - M Z (Phi x0 + F0) - M H0
+ * (getDEMc_out rows, mpcUtil.py:340-362), solve, x = Phi x0 + Gamma u + F0.   nu = ny = 1.
+ * Inputs (device fp64): list_A[nb,Nc*nx,nx] list_B[nb,Nc*nx,1] list_C[nb,Nc,nx] x0[nb,nx] y_meas[nb]
+ * Xs[nb,Nc*nx] Us[nb,Nc]; host: f0[nx] h0 Q[nx*nx] R rho and NORMALISED bounds.
+ * Outputs (device fp64, each may be NULL): Ge[nb,n,n] (lower triangle valid) Fe[nb,n] Le[nb,m,n]
+ * hv[nb,m] with n = Nc+1, m = 4Nc+2;  u[nb,Nc] eps[nb] xpred[nb,Nc*nx] status[nb] (int). */
+int nmpc_mpc_qp(int nb, int Nc, int nx, const double* list_A, const double* list_B, const double* list_C,
+                const double* x0, const double* y_meas, const double* Xs, const double* Us, const double* f0,
+                double h0, const double* Q, double R, double rho, double u_min, double u_max, double y_min,
+                double y_max, double* Ge, double* Fe, double* Le, double* hv, double* u, double* eps,
+                double* xpred, int* status, void* stream);
+
+/* ---- closed loop (reference: NMPC_test.py:22-320 output_NMPC_linear; plant Systems.py:79-97) -----
+ * `batch` independent controllers of the same model advance together; per step and controller:
+ * up to max_iterations passes of {LPV embedding at the predicted trajectory, condensing, QP,
+ * prediction update} until ||u - u_old||_2 < tol, then plant RK4 step, measurement, observer,
+ * logging and warm-start shift.  Controllers that have converged drop out of the later passes. */
+typedef struct nmpc_ctrl_config {
+    int batch, Nc, max_iterations, n_sim;
+    double tol;                          /* NMPC_test.py:257 */
+    double rho;                          /* slack weight, NMPC_test.py:225 */
+    double Q[16];                        /* nx*nx row-major */
+    double R;
+    double u_min, u_max, y_min, y_max;   /* NORMALISED bounds, NMPC_test.py:70-73 */
+    double u0, ustd, y0, ystd;           /* encoder.norm */
+    double dt;
+    double plant[6];                     /* unbalanced disc g, J, Km, I, M, tau (Systems.py:82-87) */
+    int n_nodes;
+    float lam[NMPC_MAX_NODES], w[NMPC_MAX_NODES];
+} nmpc_ctrl_config;
+
+int nmpc_ctrl_create(nmpc_ctrl** out, const nmpc_model* m, const nmpc_ctrl_config* cfg);
+void nmpc_ctrl_destroy(nmpc_ctrl* c);
+/* Initial condition of every controller (NMPC_test.py:100-124): x0n[nx] (host) normalised initial
+ * state, u0n normalised initial input, plant_x0[2] (host, may be NULL = 0). */
+int nmpc_ctrl_reset(nmpc_ctrl* c, const double* x0n, double u0n, const double* plant_x0, void* stream);
+/* Steps k0 .. k0+nsteps-1.  Xs[batch,n_sim+Nc,nx], Us[batch,n_sim+Nc] steady-state targets;
+ * noise[n_sim,batch] measurement noise (may be NULL).  Logs (device fp64 / int32, may be NULL):
+ * x_log[batch,n_sim+1,nx] u_log[batch,n_sim] e_log[batch,n_sim] y_log[batch,n_sim+1]
+ * y_est_log[batch,n_sim+1] lpv_counter[batch,n_sim] plan_log[batch,n_sim,Nc]; entries k+1 (x, y, y_est)
+ * and k (others) are written for every step k run. */
+int nmpc_ctrl_run(nmpc_ctrl* c, int k0, int nsteps, const double* Xs, const double* Us, const double* noise,
+                  double* x_log, double* u_log, double* e_log, double* y_log, double* y_est_log,
+                  int* lpv_counter, double* plan_log, void* stream);
+/* qp_fail[1] (host): number of (controller, pass) QP solves so far that did not return status 0.
+ * Synchronises the stream. */
+int nmpc_ctrl_stats(nmpc_ctrl* c, long long* qp_fail, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,3 +5,4 @@ from .lpv import (Jacobian, jacobians, quad_nodes, embed, lpv_int, lpv_int_C, la
                   lambda_trap, par_lpv_int)
 from .mpcutil import getPhi, getGamma, getF0, getZ, getPsi, getOmega, getDEMc, getDEMc_out  # noqa: F401
 from .qp import solve_qp  # noqa: F401
+from .nmpc import OutputUnbalancedDisc, Controller, mpc_qp, output_NMPC_linear  # noqa: F401

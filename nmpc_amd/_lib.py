@@ -32,7 +32,29 @@ SIGNATURES = {
     "nmpc_qp_solve": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p]),
+    "nmpc_mpc_qp": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int] + [c_void_p] * 7 + [c_double_p,
+                                   ctypes.c_double, c_double_p] + [ctypes.c_double] * 6 + [c_void_p] * 9),
+    "nmpc_ctrl_create": (ctypes.c_int, [ctypes.POINTER(c_void_p), c_void_p, c_void_p]),
+    "nmpc_ctrl_destroy": (None, [c_void_p]),
+    "nmpc_ctrl_reset": (ctypes.c_int, [c_void_p, c_double_p, ctypes.c_double, c_double_p, c_void_p]),
+    "nmpc_ctrl_run": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int] + [c_void_p] * 11),
+    "nmpc_ctrl_stats": (ctypes.c_int, [c_void_p, ctypes.POINTER(ctypes.c_longlong), c_void_p]),
 }
+
+MAX_NODES = 256
+
+
+class CtrlConfig(ctypes.Structure):
+    """struct nmpc_ctrl_config of include/nmpc_amd.h"""
+    _fields_ = [("batch", ctypes.c_int), ("Nc", ctypes.c_int), ("max_iterations", ctypes.c_int),
+                ("n_sim", ctypes.c_int), ("tol", ctypes.c_double), ("rho", ctypes.c_double),
+                ("Q", ctypes.c_double * 16), ("R", ctypes.c_double),
+                ("u_min", ctypes.c_double), ("u_max", ctypes.c_double), ("y_min", ctypes.c_double),
+                ("y_max", ctypes.c_double), ("u0", ctypes.c_double), ("ustd", ctypes.c_double),
+                ("y0", ctypes.c_double), ("ystd", ctypes.c_double), ("dt", ctypes.c_double),
+                ("plant", ctypes.c_double * 6), ("n_nodes", ctypes.c_int),
+                ("lam", ctypes.c_float * MAX_NODES), ("w", ctypes.c_float * MAX_NODES)]
+
 
 _lib = None
 

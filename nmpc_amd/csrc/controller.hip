@@ -1,0 +1,621 @@
+// Closed-loop LPV-NMPC step (reference: NMPC_test.py:149-315) for a batch of independent
+// controllers, and the stand-alone condensed MPC QP (NMPC_test.py:206-238).
+//
+// Per LPV pass two kernels run: the MFMA embedding (embed.hip) over the scheduling points of the
+// still-active controllers, then `mpc_solve_kernel`, in which one lane group per controller
+//   - scans the prefix products P_m = A_m P_{m-1} and their running sum in LDS,
+//   - forms the free response xi_i = Phi_i x0 + F0_i and Gamma_{i,j} = P_{i-j} B_j,
+//   - assembles G, F, the constraint rows [M Z Gamma + E, -1] and h directly in the solver's LDS
+//     layout (Phi, Gamma, L never touch HBM),
+//   - solves the QP (qp_gi.h), updates the predicted trajectory and tests ||u - u_old|| < tol,
+//   - appends itself to the next pass's work list if it has not converged.
+// `plant_kernel` then advances plant, measurement, observer, logs and the warm-start shift.
+#include <cstring>
+#include <vector>
+
+#include "../../include/nmpc_amd.h"
+#include "common.h"
+#include "embed.h"
+#include "qp_gi.h"
+
+namespace nmpc {
+
+struct MpcConst {
+    int Nc;
+    double Q[16];
+    double R, rho, umin, umax, ymin, ymax, h0;
+    double f0[4];
+};
+
+// LDS carve for one controller's condensing + QP
+struct MpcLds {
+    QPWork qp;
+    double *Ak, *Bk, *Ck, *Pk, *Sk, *xi, *Gam, *x0, *Xs, *Us, *uold;
+    __device__ void carve(double* base, int Nc, int nx) {
+        const int n = Nc + 1, mt = 4 * Nc + 2;
+        qp.carve(base, n, mt);
+        double* p = base + qp_lds_doubles(n, mt);
+        Ak = p; p += Nc * nx * nx; Bk = p; p += Nc * nx; Ck = p; p += Nc * nx;
+        Pk = p; p += Nc * nx * nx; Sk = p; p += Nc * nx * nx; xi = p; p += Nc * nx;
+        Gam = p; p += Nc * Nc * nx; x0 = p; p += nx; Xs = p; p += Nc * nx; Us = p; p += Nc; uold = p;
+    }
+};
+__host__ __device__ inline int mpc_lds_doubles(int Nc, int nx) {
+    const int n = Nc + 1, mt = 4 * Nc + 2;
+    return qp_lds_doubles(n, mt) + 2 * Nc * nx * nx + Nc * nx * nx + 5 * Nc * nx + Nc * Nc * nx + nx + 2 * Nc + 2;
+}
+
+// Fills qp.Lm (Hessian, lower triangle), qp.xt (linear term), qp.Nt / qp.hv (constraint rows) from
+// Ak, Bk, Ck, x0, Xs, Us.  Leaves xi and Gam for mpc_predict.
+template <int GS, int NX>
+__device__ void mpc_assemble(const MpcConst& c, MpcLds& L, double ymeas, int gl) {
+    const int Nc = c.Nc, n = Nc + 1, mt = 4 * Nc + 2;
+    for (int e = gl; e < NX * NX; e += GS) {
+        const double id = (e / NX == e % NX) ? 1.0 : 0.0;
+        L.Pk[e] = id; L.Sk[e] = id;
+    }
+    g_sync();
+    for (int m = 1; m < Nc; ++m) {
+        for (int e = gl; e < NX * NX; e += GS) {
+            const int r = e / NX, cc = e % NX;
+            double a = 0.0;
+#pragma unroll
+            for (int l = 0; l < NX; ++l) a += L.Ak[(m * NX + r) * NX + l] * L.Pk[((m - 1) * NX + l) * NX + cc];
+            L.Pk[m * NX * NX + e] = a;
+            L.Sk[m * NX * NX + e] = L.Sk[(m - 1) * NX * NX + e] + a;
+        }
+        g_sync();
+    }
+    double a0x[NX];
+#pragma unroll
+    for (int l = 0; l < NX; ++l) {
+        double a = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < NX; ++cc) a += L.Ak[l * NX + cc] * L.x0[cc];
+        a0x[l] = a;
+    }
+    for (int e = gl; e < Nc * NX; e += GS) {
+        double a = 0.0;
+#pragma unroll
+        for (int l = 0; l < NX; ++l) a += L.Pk[e * NX + l] * a0x[l] + L.Sk[e * NX + l] * c.f0[l];
+        L.xi[e] = a;
+    }
+    for (int e = gl; e < Nc * Nc * NX; e += GS) {
+        const int i = e / (Nc * NX), j = (e / NX) % Nc, r = e % NX;
+        double a = 0.0;
+        if (j <= i) {
+#pragma unroll
+            for (int l = 0; l < NX; ++l) a += L.Pk[((i - j) * NX + r) * NX + l] * L.Bk[j * NX + l];
+        }
+        L.Gam[e] = a;
+    }
+    g_sync();
+    double* Lm = L.qp.Lm; double* Nt = L.qp.Nt;
+    for (int e = gl; e < n * n; e += GS) {
+        const int a_ = e / n, b_ = e % n;
+        double v = 0.0;
+        if (a_ < Nc && b_ <= a_) {
+            for (int i = a_; i < Nc; ++i) {
+#pragma unroll
+                for (int r = 0; r < NX; ++r) {
+                    double qg = 0.0;
+#pragma unroll
+                    for (int l = 0; l < NX; ++l) qg += c.Q[r * NX + l] * L.Gam[(i * Nc + b_) * NX + l];
+                    v += L.Gam[(i * Nc + a_) * NX + r] * qg;
+                }
+            }
+            v = 2.0 * (v + (a_ == b_ ? c.R : 0.0));
+        } else if (a_ == Nc && b_ == Nc) {
+            v = c.rho;
+        }
+        Lm[e] = v;
+    }
+    for (int a_ = gl; a_ < n; a_ += GS) {
+        double v = 0.0;
+        if (a_ < Nc) {
+            for (int i = a_; i < Nc; ++i) {
+#pragma unroll
+                for (int r = 0; r < NX; ++r) {
+                    double qd = 0.0;
+#pragma unroll
+                    for (int l = 0; l < NX; ++l) qd += c.Q[r * NX + l] * (L.xi[i * NX + l] - L.Xs[i * NX + l]);
+                    v += L.Gam[(i * Nc + a_) * NX + r] * qd;
+                }
+            }
+            v = 2.0 * (v - c.R * L.Us[a_]);
+        }
+        L.qp.xt[a_] = v;
+    }
+    // rows 4i+{0,1}: -/+ u_i;  4i+{2,3}: -/+ y_i (y_0 measured, y_i = C_{i-1} x_i + h0);  last two: -/+ y_Nc
+    for (int row = gl; row < mt; row += GS) {
+        const int blk = row < 4 * Nc ? row / 4 : Nc;
+        const int kind = row < 4 * Nc ? row % 4 : 2 + (row - 4 * Nc);
+        const double sg = (kind & 1) ? 1.0 : -1.0;
+        for (int k = 0; k < Nc; ++k) Nt[k * mt + row] = 0.0;
+        Nt[Nc * mt + row] = -1.0;
+        double hval;
+        if (kind < 2) {
+            Nt[blk * mt + row] = sg;
+            hval = kind == 0 ? -c.umin : c.umax;
+        } else {
+            double yv = ymeas;
+            if (blk > 0) {
+                const int i = blk - 1;
+                for (int k = 0; k <= i; ++k) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) a += L.Ck[i * NX + r] * L.Gam[(i * Nc + k) * NX + r];
+                    Nt[k * mt + row] = sg * a;
+                }
+                yv = c.h0;
+#pragma unroll
+                for (int r = 0; r < NX; ++r) yv += L.Ck[i * NX + r] * L.xi[i * NX + r];
+            }
+            hval = (kind == 2 ? -c.ymin : c.ymax) - sg * yv;
+        }
+        L.qp.hv[row] = hval;
+    }
+    g_sync();
+}
+
+// x_pred = Phi x0 + Gamma u + F0 with u = qp.xt[0..Nc); writes into xi (in place)
+template <int GS, int NX>
+__device__ void mpc_predict(const MpcConst& c, MpcLds& L, int gl) {
+    const int Nc = c.Nc;
+    g_sync();
+    for (int e = gl; e < Nc * NX; e += GS) {
+        const int i = e / NX, r = e % NX;
+        double a = L.xi[e];
+        for (int j = 0; j <= i; ++j) a += L.Gam[(i * Nc + j) * NX + r] * L.qp.xt[j];
+        L.xi[e] = a;
+    }
+    g_sync();
+}
+
+// ---------------------------------------------------------------- stand-alone MPC QP ----------
+struct MpcQpArgs {
+    int nb, nx;
+    const double *lA, *lB, *lC, *x0, *ymeas, *Xs, *Us;
+    double *Ge, *Fe, *Le, *hv, *u, *eps, *xpred;
+    int* status;
+    MpcConst c;
+};
+
+template <int GS, int MPL, int NX>
+__global__ void mpc_qp_kernel(MpcQpArgs a) {
+    extern __shared__ __align__(16) double mpc_lds[];
+    const int gpb = blockDim.x / GS, g = threadIdx.x / GS, gl = threadIdx.x % GS;
+    const int prob = blockIdx.x * gpb + g;
+    if (prob >= a.nb) return;
+    const int Nc = a.c.Nc, n = Nc + 1, mt = 4 * Nc + 2;
+    MpcLds L;
+    L.carve(mpc_lds + (size_t)g * mpc_lds_doubles(Nc, NX), Nc, NX);
+    for (int e = gl; e < Nc * NX * NX; e += GS) L.Ak[e] = a.lA[(size_t)prob * Nc * NX * NX + e];
+    for (int e = gl; e < Nc * NX; e += GS) {
+        L.Bk[e] = a.lB[(size_t)prob * Nc * NX + e];
+        L.Ck[e] = a.lC[(size_t)prob * Nc * NX + e];
+        L.Xs[e] = a.Xs[(size_t)prob * Nc * NX + e];
+    }
+    for (int e = gl; e < Nc; e += GS) L.Us[e] = a.Us[(size_t)prob * Nc + e];
+    for (int e = gl; e < NX; e += GS) L.x0[e] = a.x0[(size_t)prob * NX + e];
+    g_sync();
+    mpc_assemble<GS, NX>(a.c, L, a.ymeas[prob], gl);
+    if (a.Ge) for (int e = gl; e < n * n; e += GS) a.Ge[(size_t)prob * n * n + e] = L.qp.Lm[e];
+    if (a.Fe) for (int e = gl; e < n; e += GS) a.Fe[(size_t)prob * n + e] = L.qp.xt[e];
+    if (a.Le) for (int e = gl; e < mt * n; e += GS) a.Le[(size_t)prob * mt * n + e] = L.qp.Nt[(e % n) * mt + e / n];
+    if (a.hv) for (int e = gl; e < mt; e += GS) a.hv[(size_t)prob * mt + e] = L.qp.hv[e];
+    if (!a.u && !a.xpred && !a.eps) return;
+    const int st = gi_solve<GS, MPL>(n, mt, 0, L.qp, nullptr, nullptr);
+    const double epsv = L.qp.xt[Nc];
+    mpc_predict<GS, NX>(a.c, L, gl);
+    if (a.u) for (int e = gl; e < Nc; e += GS) a.u[(size_t)prob * Nc + e] = L.qp.xt[e];
+    if (a.xpred) for (int e = gl; e < Nc * NX; e += GS) a.xpred[(size_t)prob * Nc * NX + e] = L.xi[e];
+    if (gl == 0) {
+        if (a.eps) a.eps[prob] = epsv;
+        if (a.status) a.status[prob] = st;
+    }
+}
+
+// ---------------------------------------------------------------- closed loop ------------------
+struct CtrlDev {
+    int B, Nc, nx, maxit, n_sim, na, nyh;   // nyh = nb + 1 output-history entries
+    double tol;
+    MpcConst c;
+    double u0, ustd, y0, ystd, dt;
+    double plant[6];
+    // state (fp64)
+    double *x0n, *xpred, *uplan, *ymeas, *xp, *uhist, *yhist, *eps;
+    int *cnt, *act, *nact;
+    unsigned long long* qp_fail;
+    // fp32 scheduling points and embedding outputs
+    float *xs32, *us32, *xc32, *A32, *B32, *C32;
+    const float *enc, *hplain;
+    int n_enc_in;
+};
+
+struct RunPtrs {
+    const double *Xs, *Us, *noise;
+    double *x_log, *u_log, *e_log, *y_log, *y_est_log, *plan_log;
+    int* lpv_counter;
+};
+
+template <int GS, int MPL, int NX>
+__global__ void mpc_solve_kernel(CtrlDev d, RunPtrs rp, int it, int k) {
+    extern __shared__ __align__(16) double mpc_lds[];
+    const int gpb = blockDim.x / GS, g = threadIdx.x / GS, gl = threadIdx.x % GS;
+    const int gid = blockIdx.x * gpb + g;
+    const int count = it == 0 ? d.B : min(d.nact[it], d.B);
+    if (gid >= count) return;
+    const int b = it == 0 ? gid : d.act[(size_t)it * d.B + gid];
+    const int Nc = d.Nc, n = Nc + 1, mt = 4 * Nc + 2, ntot = d.n_sim + Nc;
+    MpcLds L;
+    L.carve(mpc_lds + (size_t)g * mpc_lds_doubles(Nc, NX), Nc, NX);
+    for (int e = gl; e < Nc * NX * NX; e += GS) L.Ak[e] = (double)d.A32[(size_t)b * Nc * NX * NX + e];
+    for (int e = gl; e < Nc * NX; e += GS) {
+        L.Bk[e] = (double)d.B32[(size_t)b * Nc * NX + e];
+        L.Ck[e] = (double)d.C32[(size_t)b * Nc * NX + e];
+        const int i = e / NX, r = e % NX;
+        L.Xs[e] = rp.Xs[((size_t)b * ntot + (k + 1 + i)) * NX + r];
+    }
+    for (int e = gl; e < Nc; e += GS) {
+        L.Us[e] = rp.Us[(size_t)b * ntot + k + e];
+        L.uold[e] = d.uplan[(size_t)b * Nc + e];
+    }
+    for (int e = gl; e < NX; e += GS) L.x0[e] = d.x0n[(size_t)b * NX + e];
+    g_sync();
+    mpc_assemble<GS, NX>(d.c, L, d.ymeas[b], gl);
+    const int st = gi_solve<GS, MPL>(n, mt, 0, L.qp, nullptr, nullptr);
+    const double epsv = L.qp.xt[Nc];
+    mpc_predict<GS, NX>(d.c, L, gl);
+    double du = 0.0;
+    for (int e = gl; e < Nc; e += GS) {
+        const double un = L.qp.xt[e], dd = un - L.uold[e];
+        du += dd * dd;
+        d.uplan[(size_t)b * Nc + e] = un;
+        d.us32[(size_t)b * Nc + e] = (float)un;
+    }
+    du = g_sum<GS>(du);
+    for (int e = gl; e < Nc * NX; e += GS) {
+        const double xv = L.xi[e];
+        d.xpred[(size_t)b * Nc * NX + e] = xv;
+        d.xc32[(size_t)b * Nc * NX + e] = (float)xv;
+        // A_k, B_k of the next pass are scheduled at x_0 = x0n, x_k = x_pred[k-1]
+        d.xs32[(size_t)b * Nc * NX + e] = e < NX ? (float)L.x0[e] : (float)L.xi[e - NX];
+    }
+    if (gl == 0) {
+        d.eps[b] = epsv;
+        d.cnt[b] = it + 1;
+        if (st != 0) atomicAdd(d.qp_fail, 1ull);
+        if (it + 1 < d.maxit && !(sqrt(du) < d.tol)) {
+            const int pos = atomicAdd(&d.nact[it + 1], 1);
+            d.act[(size_t)(it + 1) * d.B + pos] = b;
+        }
+    }
+}
+
+// plain-layout net  W_lin z + b_lin + W4 tanh(W2 tanh(W0 z + b0) + b2) + b4  in fp64 (fp32 weights)
+template <int NOUT>
+__device__ void mlp_eval(const float* __restrict__ p, int nin, const double* in, double* out) {
+    const float* lin_w = p; const float* lin_b = lin_w + NOUT * nin;
+    const float* w0 = lin_b + NOUT; const float* b0 = w0 + HID * nin;
+    const float* w2 = b0 + HID; const float* b2 = w2 + HID * HID;
+    const float* w4 = b2 + HID; const float* b4 = w4 + NOUT * HID;
+    double t1[HID];
+#pragma unroll
+    for (int k = 0; k < HID; ++k) {
+        double a = b0[k];
+        for (int j = 0; j < nin; ++j) a += (double)w0[k * nin + j] * in[j];
+        t1[k] = tanh(a);
+    }
+#pragma unroll
+    for (int c = 0; c < NOUT; ++c) {
+        double a = (double)lin_b[c] + (double)b4[c];
+        for (int j = 0; j < nin; ++j) a += (double)lin_w[c * nin + j] * in[j];
+        out[c] = a;
+    }
+    for (int i = 0; i < HID; ++i) {
+        double a = b2[i];
+#pragma unroll
+        for (int k = 0; k < HID; ++k) a += (double)w2[i * HID + k] * t1[k];
+        const double t2 = tanh(a);
+#pragma unroll
+        for (int c = 0; c < NOUT; ++c) out[c] += (double)w4[c * HID + i] * t2;
+    }
+}
+
+__device__ __forceinline__ void disc_deriv(const double* p, double w, double th, double u, double& dw, double& dth) {
+    // Systems.py:90-94: g, J, Km, I, M, tau = p[0..5]
+    dw = -p[4] * p[0] * p[3] / p[1] * sin(th) - 1.0 / p[5] * w + p[2] / p[5] * u;
+    dth = w;
+}
+
+constexpr int MAX_HIST = 32;
+
+template <int NX>
+__global__ void plant_kernel(CtrlDev d, RunPtrs rp, int k) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0)
+        for (int it = 1; it <= d.maxit; ++it) d.nact[it] = 0;
+    if (b >= d.B) return;
+    const int Nc = d.Nc;
+    double* up = d.uplan + (size_t)b * Nc;
+    double* xpd = d.xpred + (size_t)b * Nc * NX;
+    const double u_n = up[0];
+    const double u_den = d.ustd * u_n + d.u0;                       // NMPC_test.py:271
+    // plant: one RK4 step of the disc ODE (Systems.py:90-97)
+    double w = d.xp[2 * b], th = d.xp[2 * b + 1];
+    double k1w, k1t, k2w, k2t, k3w, k3t, k4w, k4t;
+    disc_deriv(d.plant, w, th, u_den, k1w, k1t); k1w *= d.dt; k1t *= d.dt;
+    disc_deriv(d.plant, w + k1w / 2, th + k1t / 2, u_den, k2w, k2t); k2w *= d.dt; k2t *= d.dt;
+    disc_deriv(d.plant, w + k2w / 2, th + k2t / 2, u_den, k3w, k3t); k3w *= d.dt; k3t *= d.dt;
+    disc_deriv(d.plant, w + k3w, th + k3t, u_den, k4w, k4t); k4w *= d.dt; k4t *= d.dt;
+    w += (k1w + 2 * k2w + 2 * k3w + k4w) / 6;
+    th += (k1t + 2 * k2t + 2 * k3t + k4t) / 6;
+    d.xp[2 * b] = w; d.xp[2 * b + 1] = th;
+    const double y = th + (rp.noise ? rp.noise[(size_t)k * d.B + b] : 0.0);
+    const double yn = (y - d.y0) / d.ystd;                          // NMPC_test.py:280
+    d.ymeas[b] = yn;
+    // observer histories, oldest first (NMPC_test.py:283-289); net input = [u_hist, y_hist]
+    double in[MAX_HIST];
+    double* uh = d.uhist + (size_t)b * d.na;
+    double* yh = d.yhist + (size_t)b * d.nyh;
+    for (int j = 0; j < d.na; ++j) { const double v = j + 1 < d.na ? uh[j + 1] : u_n; uh[j] = v; in[j] = v; }
+    for (int j = 0; j < d.nyh; ++j) { const double v = j + 1 < d.nyh ? yh[j + 1] : yn; yh[j] = v; in[d.na + j] = v; }
+    double zest[NX], yest[1];
+    mlp_eval<NX>(d.enc, d.n_enc_in, in, zest);
+    mlp_eval<1>(d.hplain, NX, zest, yest);
+    const int ns = d.n_sim;
+    if (rp.x_log) for (int r = 0; r < NX; ++r) rp.x_log[((size_t)b * (ns + 1) + k + 1) * NX + r] = zest[r];
+    if (rp.y_log) rp.y_log[(size_t)b * (ns + 1) + k + 1] = y;
+    if (rp.y_est_log) rp.y_est_log[(size_t)b * (ns + 1) + k + 1] = d.ystd * yest[0] + d.y0;
+    if (rp.u_log) rp.u_log[(size_t)b * ns + k] = u_den;
+    if (rp.e_log) rp.e_log[(size_t)b * ns + k] = d.eps[b];
+    if (rp.lpv_counter) rp.lpv_counter[(size_t)b * ns + k] = d.cnt[b];
+    if (rp.plan_log) for (int i = 0; i < Nc; ++i) rp.plan_log[((size_t)b * ns + k) * Nc + i] = up[i];
+    // warm-start shift (NMPC_test.py:307-310) and scheduling points of the next step's first pass
+    for (int i = 0; i < Nc - 1; ++i) up[i] = up[i + 1];
+    for (int e = 0; e < (Nc - 1) * NX; ++e) xpd[e] = xpd[e + NX];
+    for (int r = 0; r < NX; ++r) d.x0n[(size_t)b * NX + r] = zest[r];
+    for (int i = 0; i < Nc; ++i) d.us32[(size_t)b * Nc + i] = (float)up[i];
+    for (int e = 0; e < Nc * NX; ++e) {
+        d.xc32[(size_t)b * Nc * NX + e] = (float)xpd[e];
+        d.xs32[(size_t)b * Nc * NX + e] = e < NX ? (float)zest[e] : (float)xpd[e - NX];
+    }
+}
+
+template <int NX>
+__global__ void reset_kernel(CtrlDev d, double u0n, double x0a, double x0b, double x0c, double x0d, double pw, double pth) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0) {
+        for (int it = 0; it <= d.maxit; ++it) d.nact[it] = 0;
+        *d.qp_fail = 0ull;
+    }
+    if (b >= d.B) return;
+    const double x0[4] = {x0a, x0b, x0c, x0d};
+    const int Nc = d.Nc;
+    for (int r = 0; r < NX; ++r) d.x0n[(size_t)b * NX + r] = x0[r];
+    for (int e = 0; e < Nc * NX; ++e) {
+        d.xpred[(size_t)b * Nc * NX + e] = x0[e % NX];
+        d.xc32[(size_t)b * Nc * NX + e] = (float)x0[e % NX];
+        d.xs32[(size_t)b * Nc * NX + e] = (float)x0[e % NX];
+    }
+    for (int i = 0; i < Nc; ++i) { d.uplan[(size_t)b * Nc + i] = u0n; d.us32[(size_t)b * Nc + i] = (float)u0n; }
+    d.ymeas[b] = 0.0; d.eps[b] = 0.0; d.cnt[b] = 0;
+    d.xp[2 * b] = pw; d.xp[2 * b + 1] = pth;
+    for (int j = 0; j < d.na; ++j) d.uhist[(size_t)b * d.na + j] = 0.0;
+    for (int j = 0; j < d.nyh; ++j) d.yhist[(size_t)b * d.nyh + j] = 0.0;
+}
+
+static int pick_gs(int Nc) {
+    int GS = 64;
+    if (const char* e = getenv("NMPC_MPC_GS")) {
+        const int v = atoi(e);
+        if ((v == 16 || v == 64) && Nc + 1 <= v) GS = v;
+    }
+    return GS;
+}
+
+// launch geometry shared by the stand-alone MPC QP and the closed-loop solve kernel
+struct MpcGeom { int GS, gpb, mpl; size_t lds; };
+static int mpc_geom(int Nc, int nx, MpcGeom& g) {
+    NMPC_REQUIRE(Nc >= 1 && Nc + 1 <= 64, "horizon Nc=%d unsupported (1..63)", Nc);
+    NMPC_REQUIRE(nx >= 1 && nx <= 4, "nx=%d unsupported by the MPC kernels (1..4)", nx);
+    g.GS = pick_gs(Nc);
+    const size_t per = sizeof(double) * (size_t)mpc_lds_doubles(Nc, nx);
+    NMPC_REQUIRE(per * (64 / g.GS) <= 160 * 1024, "horizon Nc=%d needs %zu bytes of LDS per controller: too large", Nc, per);
+    const int per_wave = 64 / g.GS;
+    int waves = (int)((48 * 1024) / (per * per_wave));
+    waves = waves < 1 ? 1 : (waves > 4 ? 4 : waves);
+    g.gpb = waves * per_wave;
+    g.lds = per * g.gpb;
+    g.mpl = (4 * Nc + 2 + g.GS - 1) / g.GS;
+    return 0;
+}
+
+}  // namespace nmpc
+
+using namespace nmpc;
+
+template <typename K>
+static int set_lds_attr(K kernel) {
+    NMPC_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return 0;
+}
+
+template <int GS, int MPL, int NX>
+static int launch_mpc_qp(const MpcQpArgs& a, const MpcGeom& g, hipStream_t s) {
+    static bool once = false;
+    if (!once) { if (set_lds_attr(mpc_qp_kernel<GS, MPL, NX>)) return 1; once = true; }
+    hipLaunchKernelGGL((mpc_qp_kernel<GS, MPL, NX>), dim3((a.nb + g.gpb - 1) / g.gpb), dim3(g.gpb * GS), g.lds, s, a);
+    NMPC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <int GS, int MPL, int NX>
+static int launch_mpc_solve(const CtrlDev& d, const RunPtrs& rp, int it, int k, const MpcGeom& g, hipStream_t s) {
+    static bool once = false;
+    if (!once) { if (set_lds_attr(mpc_solve_kernel<GS, MPL, NX>)) return 1; once = true; }
+    hipLaunchKernelGGL((mpc_solve_kernel<GS, MPL, NX>), dim3((d.B + g.gpb - 1) / g.gpb), dim3(g.gpb * GS), g.lds, s, d, rp, it, k);
+    NMPC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// (GS, MPL) pairs instantiated: GS=16 rows/lane 1..4 (Nc <= 15), GS=64 rows/lane 1, 2, 4 (Nc <= 63)
+#define NMPC_GEOM_SWITCH(FN, NX_, g, ...)                                         \
+    if (g.GS == 16 && g.mpl <= 1) return FN<16, 1, NX_>(__VA_ARGS__);             \
+    if (g.GS == 16 && g.mpl <= 2) return FN<16, 2, NX_>(__VA_ARGS__);             \
+    if (g.GS == 16 && g.mpl <= 3) return FN<16, 3, NX_>(__VA_ARGS__);             \
+    if (g.GS == 16 && g.mpl <= 4) return FN<16, 4, NX_>(__VA_ARGS__);             \
+    if (g.GS == 64 && g.mpl <= 1) return FN<64, 1, NX_>(__VA_ARGS__);             \
+    if (g.GS == 64 && g.mpl <= 2) return FN<64, 2, NX_>(__VA_ARGS__);             \
+    if (g.GS == 64 && g.mpl <= 4) return FN<64, 4, NX_>(__VA_ARGS__);
+
+static int dispatch_mpc_qp(const MpcQpArgs& a, const MpcGeom& g, hipStream_t s) {
+    if (a.nx == 2) { NMPC_GEOM_SWITCH(launch_mpc_qp, 2, g, a, g, s) }
+    if (a.nx == 3) { NMPC_GEOM_SWITCH(launch_mpc_qp, 3, g, a, g, s) }
+    set_error("nmpc_mpc_qp: no kernel for nx=%d GS=%d rows/lane=%d", a.nx, g.GS, g.mpl);
+    return 1;
+}
+
+static int dispatch_mpc_solve(const CtrlDev& d, const RunPtrs& rp, int it, int k, const MpcGeom& g, hipStream_t s) {
+    if (d.nx == 2) { NMPC_GEOM_SWITCH(launch_mpc_solve, 2, g, d, rp, it, k, g, s) }
+    if (d.nx == 3) { NMPC_GEOM_SWITCH(launch_mpc_solve, 3, g, d, rp, it, k, g, s) }
+    set_error("nmpc_ctrl_run: no kernel for nx=%d GS=%d rows/lane=%d", d.nx, g.GS, g.mpl);
+    return 1;
+}
+
+static void fill_const(MpcConst& c, int Nc, int nx, const double* Q, double R, double rho, double umin, double umax,
+                       double ymin, double ymax, const double* f0, double h0) {
+    std::memset(&c, 0, sizeof(c));
+    c.Nc = Nc;
+    for (int e = 0; e < nx * nx; ++e) c.Q[e] = Q[e];
+    for (int r = 0; r < nx; ++r) c.f0[r] = f0[r];
+    c.R = R; c.rho = rho; c.umin = umin; c.umax = umax; c.ymin = ymin; c.ymax = ymax; c.h0 = h0;
+}
+
+extern "C" int nmpc_mpc_qp(int nb, int Nc, int nx, const double* list_A, const double* list_B, const double* list_C,
+                           const double* x0, const double* y_meas, const double* Xs, const double* Us,
+                           const double* f0, double h0, const double* Q, double R, double rho, double u_min,
+                           double u_max, double y_min, double y_max, double* Ge, double* Fe, double* Le, double* hv,
+                           double* u, double* eps, double* xpred, int* status, void* stream) {
+    NMPC_REQUIRE(nb >= 0, "nmpc_mpc_qp: negative batch");
+    NMPC_REQUIRE(list_A && list_B && list_C && x0 && y_meas && Xs && Us && f0 && Q, "nmpc_mpc_qp: null input");
+    if (nb == 0) return 0;
+    MpcGeom g;
+    if (mpc_geom(Nc, nx, g)) return 1;
+    MpcQpArgs a{};
+    a.nb = nb; a.nx = nx; a.lA = list_A; a.lB = list_B; a.lC = list_C; a.x0 = x0; a.ymeas = y_meas; a.Xs = Xs; a.Us = Us;
+    a.Ge = Ge; a.Fe = Fe; a.Le = Le; a.hv = hv; a.u = u; a.eps = eps; a.xpred = xpred; a.status = status;
+    fill_const(a.c, Nc, nx, Q, R, rho, u_min, u_max, y_min, y_max, f0, h0);
+    return dispatch_mpc_qp(a, g, (hipStream_t)stream);
+}
+
+struct nmpc_ctrl {
+    CtrlDev d;
+    ModelDev m;
+    NodeTable nt;
+    MpcGeom g;
+    std::vector<void*> allocs;
+    int device;
+};
+
+extern "C" int nmpc_ctrl_create(nmpc_ctrl** out, const nmpc_model* m, const nmpc_ctrl_config* cfg) {
+    NMPC_REQUIRE(out && m && cfg, "nmpc_ctrl_create: null argument");
+    NMPC_REQUIRE(m->d.nu == 1 && m->d.ny == 1, "nmpc_ctrl_create: closed loop needs nu = ny = 1 (as the reference)");
+    NMPC_REQUIRE(m->d.enc && m->d.n_enc_in <= MAX_HIST, "nmpc_ctrl_create: model has no observer net");
+    NMPC_REQUIRE(cfg->batch >= 1 && cfg->max_iterations >= 1 && cfg->max_iterations <= 64 && cfg->n_sim >= 1,
+                 "nmpc_ctrl_create: bad batch/max_iterations/n_sim");
+    NMPC_REQUIRE(cfg->n_nodes >= 1 && cfg->n_nodes <= NMPC_MAX_NODES, "nmpc_ctrl_create: bad node count");
+    nmpc_ctrl* c = new nmpc_ctrl();
+    if (mpc_geom(cfg->Nc, m->d.nx, c->g)) { delete c; return 1; }
+    c->m = m->d;
+    NMPC_HIP_CHECK(hipGetDevice(&c->device));
+    CtrlDev& d = c->d;
+    std::memset(&d, 0, sizeof(d));
+    const int B = cfg->batch, Nc = cfg->Nc, nx = m->d.nx;
+    d.B = B; d.Nc = Nc; d.nx = nx; d.maxit = cfg->max_iterations; d.n_sim = cfg->n_sim;
+    d.n_enc_in = m->d.n_enc_in;
+    d.na = (d.n_enc_in - 1) / 2; d.nyh = d.n_enc_in - d.na;        // nb inputs, na+1 outputs (na_right = 1)
+    d.tol = cfg->tol;
+    fill_const(d.c, Nc, nx, cfg->Q, cfg->R, cfg->rho, cfg->u_min, cfg->u_max, cfg->y_min, cfg->y_max, m->d.f0, m->d.h0[0]);
+    d.u0 = cfg->u0; d.ustd = cfg->ustd; d.y0 = cfg->y0; d.ystd = cfg->ystd; d.dt = cfg->dt;
+    for (int i = 0; i < 6; ++i) d.plant[i] = cfg->plant[i];
+    d.enc = m->d.enc; d.hplain = m->d.hplain;
+    c->nt.n = cfg->n_nodes;
+    for (int i = 0; i < NMPC_MAX_NODES; ++i) { c->nt.lam[i] = i < cfg->n_nodes ? cfg->lam[i] : 0.f; c->nt.w[i] = i < cfg->n_nodes ? cfg->w[i] : 0.f; }
+    auto alloc = [&](void** p, size_t bytes) -> int {
+        NMPC_HIP_CHECK(hipMalloc(p, bytes));
+        NMPC_HIP_CHECK(hipMemset(*p, 0, bytes));
+        c->allocs.push_back(*p);
+        return 0;
+    };
+    const size_t sb = (size_t)B;
+    int rc = 0;
+    rc |= alloc((void**)&d.x0n, sb * nx * 8); rc |= alloc((void**)&d.xpred, sb * Nc * nx * 8);
+    rc |= alloc((void**)&d.uplan, sb * Nc * 8); rc |= alloc((void**)&d.ymeas, sb * 8);
+    rc |= alloc((void**)&d.xp, sb * 2 * 8); rc |= alloc((void**)&d.uhist, sb * d.na * 8);
+    rc |= alloc((void**)&d.yhist, sb * d.nyh * 8); rc |= alloc((void**)&d.eps, sb * 8);
+    rc |= alloc((void**)&d.cnt, sb * 4); rc |= alloc((void**)&d.act, sb * (d.maxit + 1) * 4);
+    rc |= alloc((void**)&d.nact, (d.maxit + 2) * 4); rc |= alloc((void**)&d.qp_fail, 8);
+    rc |= alloc((void**)&d.xs32, sb * Nc * nx * 4); rc |= alloc((void**)&d.us32, sb * Nc * 4);
+    rc |= alloc((void**)&d.xc32, sb * Nc * nx * 4); rc |= alloc((void**)&d.A32, sb * Nc * nx * nx * 4);
+    rc |= alloc((void**)&d.B32, sb * Nc * nx * 4); rc |= alloc((void**)&d.C32, sb * Nc * nx * 4);
+    if (rc) { nmpc_ctrl_destroy(c); return 1; }
+    *out = c;
+    return 0;
+}
+
+extern "C" void nmpc_ctrl_destroy(nmpc_ctrl* c) {
+    if (!c) return;
+    for (void* p : c->allocs) (void)hipFree(p);
+    delete c;
+}
+
+extern "C" int nmpc_ctrl_reset(nmpc_ctrl* c, const double* x0n, double u0n, const double* plant_x0, void* stream) {
+    NMPC_REQUIRE(c && x0n, "nmpc_ctrl_reset: null argument");
+    double x0[4] = {0, 0, 0, 0};
+    for (int r = 0; r < c->d.nx; ++r) x0[r] = x0n[r];
+    const double pw = plant_x0 ? plant_x0[0] : 0.0, pth = plant_x0 ? plant_x0[1] : 0.0;
+    const int threads = 128, grid = (c->d.B + threads - 1) / threads;
+    if (c->d.nx == 2) hipLaunchKernelGGL((reset_kernel<2>), dim3(grid), dim3(threads), 0, (hipStream_t)stream, c->d, u0n, x0[0], x0[1], x0[2], x0[3], pw, pth);
+    else if (c->d.nx == 3) hipLaunchKernelGGL((reset_kernel<3>), dim3(grid), dim3(threads), 0, (hipStream_t)stream, c->d, u0n, x0[0], x0[1], x0[2], x0[3], pw, pth);
+    else { set_error("nmpc_ctrl_reset: nx=%d unsupported", c->d.nx); return 1; }
+    NMPC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int nmpc_ctrl_run(nmpc_ctrl* c, int k0, int nsteps, const double* Xs, const double* Us, const double* noise,
+                             double* x_log, double* u_log, double* e_log, double* y_log, double* y_est_log,
+                             int* lpv_counter, double* plan_log, void* stream) {
+    NMPC_REQUIRE(c && Xs && Us, "nmpc_ctrl_run: null argument");
+    NMPC_REQUIRE(k0 >= 0 && nsteps >= 0 && k0 + nsteps <= c->d.n_sim, "nmpc_ctrl_run: steps [%d,%d) outside n_sim=%d", k0,
+                 k0 + nsteps, c->d.n_sim);
+    hipStream_t s = (hipStream_t)stream;
+    const CtrlDev& d = c->d;
+    RunPtrs rp{Xs, Us, noise, x_log, u_log, e_log, y_log, y_est_log, plan_log, lpv_counter};
+    for (int k = k0; k < k0 + nsteps; ++k) {
+        for (int it = 0; it < d.maxit; ++it) {
+            EmbedArgs a{};
+            a.x = d.xs32; a.u = d.us32; a.xc = d.xc32; a.A = d.A32; a.B = d.B32; a.C = d.C32;
+            a.npts = d.B * d.Nc; a.group = d.Nc;
+            if (it > 0) { a.count_dev = d.nact + it; a.act = d.act + (size_t)it * d.B; }
+            if (embed_launch(c->m, a, c->nt, s)) return 1;
+            if (dispatch_mpc_solve(d, rp, it, k, c->g, s)) return 1;
+        }
+        const int threads = 64, grid = (d.B + threads - 1) / threads;
+        if (d.nx == 2) hipLaunchKernelGGL((plant_kernel<2>), dim3(grid), dim3(threads), 0, s, d, rp, k);
+        else if (d.nx == 3) hipLaunchKernelGGL((plant_kernel<3>), dim3(grid), dim3(threads), 0, s, d, rp, k);
+        else { set_error("nmpc_ctrl_run: nx=%d unsupported", d.nx); return 1; }
+        NMPC_HIP_CHECK(hipGetLastError());
+    }
+    return 0;
+}
+
+extern "C" int nmpc_ctrl_stats(nmpc_ctrl* c, long long* qp_fail, void* stream) {
+    NMPC_REQUIRE(c && qp_fail, "nmpc_ctrl_stats: null argument");
+    unsigned long long v = 0;
+    NMPC_HIP_CHECK(hipMemcpyAsync(&v, c->d.qp_fail, 8, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    NMPC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    *qp_fail = (long long)v;
+    return 0;
+}

@@ -94,14 +94,16 @@ extern "C" int nmpc_model_create(nmpc_model** out, int nx, int nu, int ny, int h
     NMPC_HIP_CHECK(hipMemcpy(m->d.hpack, buf.data(), PACK_FLOATS * sizeof(float), hipMemcpyHostToDevice));
     eval_net_at_zero(fn, nx + nu, nx, hidden, m->d.f0);
     eval_net_at_zero(hn, nx, ny, hidden, m->d.h0);
-    if (enc) {
-        // plain concatenation: lin_w[nx,in] lin_b[nx] w0[H,in] b0[H] w2[H,H] b2[H] w4[nx,H] b4[nx]
-        const int sz[8] = {nx * n_enc_in, nx, hidden * n_enc_in, hidden, hidden * hidden, hidden, nx * hidden, nx};
+    auto upload_plain = [&](const float* const* p, int n_in, int n_out, float** dst) -> int {
+        const int sz[8] = {n_out * n_in, n_out, hidden * n_in, hidden, hidden * hidden, hidden, n_out * hidden, n_out};
         std::vector<float> e;
-        for (int i = 0; i < 8; ++i) e.insert(e.end(), enc[i], enc[i] + sz[i]);
-        NMPC_HIP_CHECK(hipMalloc(&m->d.enc, e.size() * sizeof(float)));
-        NMPC_HIP_CHECK(hipMemcpy(m->d.enc, e.data(), e.size() * sizeof(float), hipMemcpyHostToDevice));
-    }
+        for (int i = 0; i < 8; ++i) e.insert(e.end(), p[i], p[i] + sz[i]);
+        NMPC_HIP_CHECK(hipMalloc(dst, e.size() * sizeof(float)));
+        NMPC_HIP_CHECK(hipMemcpy(*dst, e.data(), e.size() * sizeof(float), hipMemcpyHostToDevice));
+        return 0;
+    };
+    if (upload_plain(hn, nx, ny, &m->d.hplain)) return 1;
+    if (enc && upload_plain(enc, n_enc_in, nx, &m->d.enc)) return 1;
     *out = m;
     return 0;
 }
@@ -111,6 +113,7 @@ extern "C" void nmpc_model_destroy(nmpc_model* m) {
     if (m->d.fpack) (void)hipFree(m->d.fpack);
     if (m->d.hpack) (void)hipFree(m->d.hpack);
     if (m->d.enc) (void)hipFree(m->d.enc);
+    if (m->d.hplain) (void)hipFree(m->d.hplain);
     delete m;
 }
 

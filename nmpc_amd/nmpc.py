@@ -1,0 +1,215 @@
+"""Closed-loop LPV-NMPC controllers with the reference's call signatures, batched over
+independent controllers (scenarios / references / noise seeds) on one GPU.
+
+output_NMPC_linear follows NMPC_test.py:22-320: every array the reference returns comes back with
+a leading batch dimension (dropped again when a single 1-D reference is passed)."""
+import ctypes
+import time
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check, ptr, current_stream
+from .lpv import quad_nodes
+from .mpcutil import _f64
+
+
+class OutputUnbalancedDisc:
+    """Plant descriptor with the constants of Systems.py:79-97 (angle output + N(0, sigma_n))."""
+    g = 9.80155078791343
+    J = 0.000244210523960356
+    Km = 10.5081817407479
+    I = 0.0410772235841364
+    M = 0.0761844495320390
+    tau = 0.397973147009910
+
+    def __init__(self, dt=0.025, sigma_n=(0,), seed=0):
+        self.dt = float(dt)
+        self.sigma_n = list(sigma_n)
+        self.seed = int(seed)
+        self.nx = 2
+        self.x0 = np.zeros(2)
+
+    def reset_state(self):
+        self.x0 = np.zeros(2)
+
+    def params(self):
+        return [self.g, self.J, self.Km, self.I, self.M, self.tau]
+
+
+def mpc_qp(list_A, list_B, list_C, x0, y_meas, Xs, Us, f0, h0, Q, R, rho, u_min, u_max, y_min, y_max, Nc, nx,
+           want_matrices=False):
+    """One condensed QP of the output-constrained controller (NMPC_test.py:206-238), batched.
+    Returns dict(u, eps, xpred, status[, Ge, Fe, Le, h])."""
+    lA = _f64(list_A); dev = lA.device
+    batch = lA.shape[:-2]
+    nb = int(np.prod(batch)) if len(batch) else 1
+    lB = _f64(list_B, dev).reshape(batch + (Nc * nx,)); lC = _f64(list_C, dev).reshape(batch + (Nc, nx))
+    x0 = _f64(x0, dev).reshape(batch + (nx,)); ym = _f64(y_meas, dev).reshape(batch)
+    Xs = _f64(Xs, dev).reshape(batch + (Nc * nx,)); Us = _f64(Us, dev).reshape(batch + (Nc,))
+    n, m = Nc + 1, 4 * Nc + 2
+    mk = lambda *s: torch.empty(batch + s, dtype=torch.float64, device=dev)
+    out = dict(u=mk(Nc), eps=mk(), xpred=mk(Nc * nx), status=torch.empty(batch, dtype=torch.int32, device=dev))
+    if want_matrices:
+        out.update(Ge=mk(n, n), Fe=mk(n), Le=mk(m, n), h=mk(m))
+    f0a = np.ascontiguousarray(np.asarray(f0, np.float64).reshape(-1))
+    Qa = np.ascontiguousarray(np.asarray(Q, np.float64).reshape(nx, nx))
+    R = float(np.asarray(R).reshape(-1)[0])
+    with torch.cuda.device(dev):
+        rc = lib().nmpc_mpc_qp(nb, Nc, nx, ptr(lA), ptr(lB), ptr(lC), ptr(x0), ptr(ym), ptr(Xs), ptr(Us),
+                               f0a.ctypes.data_as(_lib.c_double_p), float(np.asarray(h0).reshape(-1)[0]),
+                               Qa.ctypes.data_as(_lib.c_double_p), R, float(rho), float(u_min), float(u_max),
+                               float(y_min), float(y_max), ptr(out.get("Ge")), ptr(out.get("Fe")),
+                               ptr(out.get("Le")), ptr(out.get("h")), ptr(out["u"]), ptr(out["eps"]),
+                               ptr(out["xpred"]), ptr(out["status"]), current_stream())
+    check(rc, "nmpc_mpc_qp")
+    return out
+
+
+class Controller:
+    """Batch of closed-loop controllers resident on the GPU (nmpc_ctrl of the C ABI)."""
+
+    def __init__(self, encoder, system, batch, Nc, Nsim, max_iterations, Q, R, u_min_n, u_max_n, y_min_n, y_max_n,
+                 nodes, weights, tol=1e-1, rho=1000.0):
+        cfg = _lib.CtrlConfig()
+        cfg.batch, cfg.Nc, cfg.max_iterations, cfg.n_sim = int(batch), int(Nc), int(max_iterations), int(Nsim)
+        cfg.tol, cfg.rho = float(tol), float(rho)
+        Qa = np.asarray(Q, np.float64).reshape(encoder.nx, encoder.nx)
+        for i, v in enumerate(Qa.reshape(-1)):
+            cfg.Q[i] = float(v)
+        cfg.R = float(np.asarray(R).reshape(-1)[0])
+        cfg.u_min, cfg.u_max, cfg.y_min, cfg.y_max = float(u_min_n), float(u_max_n), float(y_min_n), float(y_max_n)
+        nm = encoder.norm
+        cfg.u0, cfg.ustd, cfg.y0, cfg.ystd = nm.u0, nm.ustd, nm.y0, nm.ystd
+        cfg.dt = float(system.dt)
+        for i, v in enumerate(system.params()):
+            cfg.plant[i] = float(v)
+        cfg.n_nodes = len(nodes)
+        for i in range(len(nodes)):
+            cfg.lam[i] = float(nodes[i]); cfg.w[i] = float(weights[i])
+        self.encoder, self.cfg = encoder, cfg
+        self.B, self.Nc, self.Nsim, self.nx = int(batch), int(Nc), int(Nsim), encoder.nx
+        h = ctypes.c_void_p()
+        with torch.cuda.device(encoder.device):
+            rc = lib().nmpc_ctrl_create(ctypes.byref(h), encoder.handle, ctypes.byref(cfg))
+        check(rc, "nmpc_ctrl_create")
+        self.handle = h
+        dev = encoder.device
+        z = lambda *s, dt=torch.float64: torch.zeros(s, dtype=dt, device=dev)
+        B, Ns = self.B, self.Nsim
+        self.logs = dict(x_log=z(B, Ns + 1, self.nx), u_log=z(B, Ns), e_log=z(B, Ns), y_log=z(B, Ns + 1),
+                         y_est_log=z(B, Ns + 1), lpv_counter=z(B, Ns, dt=torch.int32), plan_log=z(B, Ns, Nc))
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h:
+            try:
+                lib().nmpc_ctrl_destroy(h)
+            except Exception:
+                pass
+            self.handle = None
+
+    def reset(self, x0n, u0n, plant_x0=None):
+        x0a = np.ascontiguousarray(np.asarray(x0n, np.float64).reshape(-1))
+        px = None if plant_x0 is None else np.ascontiguousarray(np.asarray(plant_x0, np.float64).reshape(-1))
+        with torch.cuda.device(self.encoder.device):
+            rc = lib().nmpc_ctrl_reset(self.handle, x0a.ctypes.data_as(_lib.c_double_p), float(u0n),
+                                       None if px is None else px.ctypes.data_as(_lib.c_double_p), current_stream())
+        check(rc, "nmpc_ctrl_reset")
+
+    def set_targets(self, Xs, Us, noise=None):
+        """Xs [B, Nsim+Nc, nx], Us [B, Nsim+Nc], noise [Nsim, B] (device fp64)."""
+        dev = self.encoder.device
+        self.Xs = _f64(Xs, dev).reshape(self.B, self.Nsim + self.Nc, self.nx)
+        self.Us = _f64(Us, dev).reshape(self.B, self.Nsim + self.Nc)
+        self.noise = None if noise is None else _f64(noise, dev).reshape(self.Nsim, self.B)
+
+    def run(self, k0, nsteps):
+        L = self.logs
+        with torch.cuda.device(self.encoder.device):
+            rc = lib().nmpc_ctrl_run(self.handle, int(k0), int(nsteps), ptr(self.Xs), ptr(self.Us), ptr(self.noise),
+                                     ptr(L["x_log"]), ptr(L["u_log"]), ptr(L["e_log"]), ptr(L["y_log"]),
+                                     ptr(L["y_est_log"]), ptr(L["lpv_counter"]), ptr(L["plan_log"]), current_stream())
+        check(rc, "nmpc_ctrl_run")
+
+    def qp_failures(self):
+        v = ctypes.c_longlong(0)
+        with torch.cuda.device(self.encoder.device):
+            check(lib().nmpc_ctrl_stats(self.handle, ctypes.byref(v), current_stream()), "nmpc_ctrl_stats")
+        return int(v.value)
+
+
+def output_NMPC_linear(system, encoder, u_min, u_max, y_min, y_max, x0, Q, R, dt, dlam, stages, y_reference_list,
+                       Nc=5, Nsim=30, max_iterations=1, *, tol=1e-1, rho=1000.0, targets=None, noise=None,
+                       return_controller=False):
+    """Output-constrained LPV-NMPC with observer (NMPC_test.py:22-320), batched.
+
+    y_reference_list: [B, >= Nsim+Nc] (or 1-D for one controller) output reference in physical units.
+    targets: optional (Xs [B, nx, Nsim+Nc], Us [B, nu, Nsim+Nc]) steady-state targets; computed by
+    getXsUs_Cs when omitted.  noise: optional [Nsim, B] measurement noise; drawn from
+    N(0, system.sigma_n[0]) with system.seed when omitted and sigma_n > 0.
+    Returns the reference's 12-tuple (x_log, u_log, e_log, comp_t_log, t, runtime, lpv_counter,
+    components_time, y_log, y_est_log, Xs, Us)."""
+    _lib.require_gpu()
+    dev = encoder.device
+    nx, nu, ny = encoder.nx, encoder.nu, encoder.ny
+    nm = encoder.norm
+    yref = torch.as_tensor(np.asarray(y_reference_list, np.float64))
+    single = yref.dim() == 1
+    if single:
+        yref = yref[None]
+    B = yref.shape[0]
+    assert yref.shape[1] >= Nsim + Nc, "reference must hold Nsim+Nc samples"
+    y_ref_n = ((yref - nm.y0) / nm.ystd)                                  # NMPC_test.py:47
+    x0 = np.asarray(x0, np.float64).reshape(nx)
+    x0n = (x0 - nm.y0) / nm.ystd                                          # NMPC_test.py:48
+    u0n = (0 - nm.u0) / nm.ustd                                           # NMPC_test.py:49-50
+    ymax_n = (float(np.asarray(y_max).reshape(-1)[0]) - nm.y0) / nm.ystd  # NMPC_test.py:70-73
+    ymin_n = (float(np.asarray(y_min).reshape(-1)[0]) - nm.y0) / nm.ystd
+    umin_n = (float(u_min) - nm.u0) / nm.ustd
+    umax_n = (float(u_max) - nm.u0) / nm.ustd
+    y_ref_n = torch.clamp(y_ref_n, ymin_n, ymax_n)                        # NMPC_test.py:76
+    lam, w = quad_nodes("simpson", stages)                                # lambda_simpson, NMPC_test.py:59
+    if targets is None:
+        from .target import getXsUs_Cs
+        Xs, Us, _ = getXsUs_Cs(y_ref_n[:, :Nsim + Nc].to(dev), nx, nu, ny, Nsim + Nc, umin_n, umax_n, [ymin_n],
+                               [ymax_n], encoder, lam, w)
+    else:
+        Xs, Us = (_f64(t, dev) for t in targets)
+        Xs = Xs.reshape(B, nx, -1)[:, :, :Nsim + Nc]; Us = Us.reshape(B, nu, -1)[:, :, :Nsim + Nc]
+    ctrl = Controller(encoder, system, B, Nc, Nsim, max_iterations, Q, R, umin_n, umax_n, ymin_n, ymax_n, lam, w,
+                      tol=tol, rho=rho)
+    if noise is None and system.sigma_n[0] > 0:
+        gen = torch.Generator(device="cpu"); gen.manual_seed(system.seed)
+        noise = torch.randn(Nsim, B, generator=gen, dtype=torch.float64) * float(system.sigma_n[0])
+    ctrl.set_targets(Xs.transpose(1, 2).contiguous(), Us[:, 0, :].contiguous(), noise)
+    ctrl.reset(x0n, u0n, getattr(system, "x0", None))
+    comp_t_log = np.zeros(Nsim)
+    torch.cuda.synchronize(dev)
+    start = time.time()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(Nsim + 1)]
+    ev[0].record()
+    for k in range(Nsim):
+        ctrl.run(k, 1)
+        ev[k + 1].record()
+    torch.cuda.synchronize(dev)
+    runtime = time.time() - start
+    for k in range(Nsim):
+        comp_t_log[k] = ev[k].elapsed_time(ev[k + 1]) * 1e-3
+    nfail = ctrl.qp_failures()
+    if nfail:
+        raise _lib.NmpcError("output_NMPC_linear: %d QP solves did not converge" % nfail)
+    L = ctrl.logs
+    x_log = L["x_log"].clone(); x_log[:, 0, :] = torch.as_tensor(x0, device=dev)   # NMPC_test.py:88
+    x_log = x_log.reshape(B, (Nsim + 1) * nx)
+    e_log = torch.zeros(B, nx, Nsim, dtype=torch.float64, device=dev); e_log[:, 0, :] = L["e_log"]
+    t = np.arange(Nsim) * dt
+    components_time = np.zeros((4, Nsim * max_iterations))
+    out = [x_log, L["u_log"], e_log, comp_t_log, t, runtime, L["lpv_counter"], components_time, L["y_log"],
+           L["y_est_log"], Xs, Us]
+    if single:
+        out = [o[0] if torch.is_tensor(o) else o for o in out]
+    if return_controller:
+        return tuple(out), ctrl
+    return tuple(out)
