@@ -133,6 +133,21 @@ int nmpc_ctrl_run(nmpc_ctrl* c, int k0, int nsteps, const double* Xs, const doub
  * Synchronises the stream. */
 int nmpc_ctrl_stats(nmpc_ctrl* c, long long* qp_fail, void* stream);
 
+/* ---- steady-state target selector (reference: mpcUtil.py:241-320 getXsUs_Cs, called pre-loop at
+ * NMPC_test.py:79-80).  For every reference sample j, warm-started from sample j-1, iterate up to
+ * max_lpv times: embed A,B,C at (xs,us); solve the reference's 4-variable QP
+ *   (I-A) xs - B us = f0,  C xs = r_j - h0,  soft input/output box with slack e (weight lam_e);
+ * stop when ||xs-xs_old|| <= tol and ||us-us_old|| <= tol.  nu = ny = 1: the nx+1 equalities
+ * determine (xs,us) and the QP reduces to e = max(0, worst box violation), which is what is
+ * computed.  y_ref_n[nb,nsamp] normalised reference (device fp64).  Outputs (device):
+ * Xs[nb,nsamp,nx] Us[nb,nsamp] Es[nb,nsamp] (fp64), iters[nb,nsamp] (int32, may be NULL),
+ * status[nb] (int32: 0 ok, 1 singular equality system met).
+ * Pre-loop set-up routine: allocates and frees its own workspace and synchronises the stream. */
+int nmpc_target_select(const nmpc_model* m, int nb, int nsamp, const double* y_ref_n, double u_min,
+                       double u_max, double y_min, double y_max, const float* lam, const float* w,
+                       int n_nodes, int max_lpv, double tol, double* Xs, double* Us, double* Es,
+                       int* iters, int* status, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,3 +6,4 @@ from .lpv import (Jacobian, jacobians, quad_nodes, embed, lpv_int, lpv_int_C, la
 from .mpcutil import getPhi, getGamma, getF0, getZ, getPsi, getOmega, getDEMc, getDEMc_out  # noqa: F401
 from .qp import solve_qp  # noqa: F401
 from .nmpc import OutputUnbalancedDisc, Controller, mpc_qp, output_NMPC_linear  # noqa: F401
+from .target import GetABC, getXsUs_Cs  # noqa: F401

@@ -1,0 +1,169 @@
+// Steady-state target selector (reference: mpcUtil.py:241-320 getXsUs_Cs), batched over
+// controllers, sequential over reference samples (each sample is warm-started from the previous
+// one, mpcUtil.py:270-271,306-307).
+//
+// The reference solves, per LPV pass, a QP in (xs, us, e) with the nx+ny equalities
+//     (I - A) xs - B us = f0,   C xs = r - h0
+// and four soft box rows  -us - e <= -umin, us - e <= umax, -C xs - e <= -ymin, C xs - e <= ymax
+// (the right-hand side is used WITHOUT the h0 shift: the (4,1)-(4,) broadcast at mpcUtil.py:254
+// followed by h[:,0] at :302 drops it).  With nu = ny = 1 the equalities are nx+1 equations in the
+// nx+1 unknowns (xs, us), so they fix (xs, us) and the QP only chooses the slack:
+// e = max(0, largest row violation).  That closed form is what the kernel evaluates (Gaussian
+// elimination with partial pivoting, fp64); a singular system is flagged in `status`.
+#include <vector>
+
+#include "../../include/nmpc_amd.h"
+#include "common.h"
+#include "embed.h"
+
+namespace nmpc {
+
+struct TargetArgs {
+    int nb, nsamp, max_lpv;
+    double tol, umin, umax, ymin, ymax, h0;
+    double f0[4];
+    const double* yref;
+    double *Xs, *Us, *Es;
+    int *iters, *status;
+    // workspace
+    double *xs, *us;
+    float *xs32, *us32, *A32, *B32, *C32;
+    int *act, *counts;
+};
+
+template <int NX>
+__global__ void target_kernel(TargetArgs a, int j, int i) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int count = i == 0 ? a.nb : min(a.counts[i], a.nb);
+    if (gid >= count) return;
+    const int b = i == 0 ? gid : a.act[(size_t)(i & 1) * a.nb + gid];
+    constexpr int N = NX + 1;
+    double M[N][N + 1];
+#pragma unroll
+    for (int r = 0; r < NX; ++r) {
+#pragma unroll
+        for (int c = 0; c < NX; ++c) M[r][c] = (r == c ? 1.0 : 0.0) - (double)a.A32[((size_t)b * NX + r) * NX + c];
+        M[r][NX] = -(double)a.B32[(size_t)b * NX + r];
+        M[r][N] = a.f0[r];
+    }
+    double Cs[NX];
+#pragma unroll
+    for (int c = 0; c < NX; ++c) { Cs[c] = (double)a.C32[(size_t)b * NX + c]; M[NX][c] = Cs[c]; }
+    M[NX][NX] = 0.0;
+    M[NX][N] = a.yref[(size_t)b * a.nsamp + j] - a.h0;
+    bool singular = false;
+#pragma unroll
+    for (int col = 0; col < N; ++col) {
+        int piv = col; double best = fabs(M[col][col]);
+#pragma unroll
+        for (int r = col + 1; r < N; ++r) if (fabs(M[r][col]) > best) { best = fabs(M[r][col]); piv = r; }
+        if (!(best > 1e-13)) { singular = true; best = 1.0; }
+#pragma unroll
+        for (int r = col + 1; r < N; ++r)
+            if (r == piv) {
+#pragma unroll
+                for (int c = 0; c <= N; ++c) { const double t = M[col][c]; M[col][c] = M[r][c]; M[r][c] = t; }
+            }
+        const double inv = 1.0 / (singular && fabs(M[col][col]) <= 1e-13 ? 1.0 : M[col][col]);
+#pragma unroll
+        for (int r = col + 1; r < N; ++r) {
+            const double f = M[r][col] * inv;
+#pragma unroll
+            for (int c = col; c <= N; ++c) M[r][c] -= f * M[col][c];
+        }
+    }
+    double z[N];
+#pragma unroll
+    for (int r = N - 1; r >= 0; --r) {
+        double v = M[r][N];
+#pragma unroll
+        for (int c = r + 1; c < N; ++c) v -= M[r][c] * z[c];
+        z[r] = v / (fabs(M[r][r]) > 1e-13 ? M[r][r] : 1.0);
+    }
+    const double usn = z[NX];
+    double cy = 0.0, dx = 0.0;
+#pragma unroll
+    for (int c = 0; c < NX; ++c) {
+        cy += Cs[c] * z[c];
+        const double d = z[c] - a.xs[(size_t)b * NX + c];
+        dx += d * d;
+    }
+    const double du = fabs(usn - a.us[b]);
+    double v = fmax(fmax(-usn + a.umin, usn - a.umax), fmax(-cy + a.ymin, cy - a.ymax));
+    const double e = v > 0.0 ? v : 0.0;
+#pragma unroll
+    for (int c = 0; c < NX; ++c) {
+        a.xs[(size_t)b * NX + c] = z[c];
+        a.xs32[(size_t)b * NX + c] = (float)z[c];
+        a.Xs[((size_t)b * a.nsamp + j) * NX + c] = z[c];
+    }
+    a.us[b] = usn; a.us32[b] = (float)usn;
+    a.Us[(size_t)b * a.nsamp + j] = usn;
+    a.Es[(size_t)b * a.nsamp + j] = e;
+    if (a.iters) a.iters[(size_t)b * a.nsamp + j] = i + 1;
+    if (singular) a.status[b] = 1;
+    const bool conv = sqrt(dx) <= a.tol && du <= a.tol;          // mpcUtil.py:310
+    if (!conv && i + 1 < a.max_lpv) {
+        const int pos = atomicAdd(&a.counts[i + 1], 1);
+        a.act[(size_t)((i + 1) & 1) * a.nb + pos] = b;
+    }
+}
+
+}  // namespace nmpc
+
+using namespace nmpc;
+
+extern "C" int nmpc_target_select(const nmpc_model* m, int nb, int nsamp, const double* y_ref_n, double u_min,
+                                  double u_max, double y_min, double y_max, const float* lam, const float* w,
+                                  int n_nodes, int max_lpv, double tol, double* Xs, double* Us, double* Es,
+                                  int* iters, int* status, void* stream) {
+    NMPC_REQUIRE(m && y_ref_n && lam && w && Xs && Us && Es && status, "nmpc_target_select: null argument");
+    NMPC_REQUIRE(m->d.nu == 1 && m->d.ny == 1, "nmpc_target_select: needs nu = ny = 1 (as the reference)");
+    NMPC_REQUIRE(nb >= 1 && nsamp >= 1 && max_lpv >= 1 && max_lpv <= 1024, "nmpc_target_select: bad sizes");
+    NMPC_REQUIRE(n_nodes >= 1 && n_nodes <= NMPC_MAX_NODES, "nmpc_target_select: bad node count");
+    hipStream_t s = (hipStream_t)stream;
+    const int nx = m->d.nx;
+    NodeTable nt;
+    nt.n = n_nodes;
+    for (int i = 0; i < NMPC_MAX_NODES; ++i) { nt.lam[i] = i < n_nodes ? lam[i] : 0.f; nt.w[i] = i < n_nodes ? w[i] : 0.f; }
+    TargetArgs a{};
+    a.nb = nb; a.nsamp = nsamp; a.max_lpv = max_lpv; a.tol = tol;
+    a.umin = u_min; a.umax = u_max; a.ymin = y_min; a.ymax = y_max; a.h0 = m->d.h0[0];
+    for (int r = 0; r < nx; ++r) a.f0[r] = m->d.f0[r];
+    a.yref = y_ref_n; a.Xs = Xs; a.Us = Us; a.Es = Es; a.iters = iters; a.status = status;
+    // one slab: xs, us (fp64) | xs32 us32 A32 B32 C32 (fp32) | act[2][nb], counts[max_lpv+1] (int)
+    const size_t nB = (size_t)nb;
+    const size_t bytes = nB * (nx + 1) * 8 + nB * (size_t)(nx + 1 + nx * nx + nx + nx) * 4 + (2 * nB + max_lpv + 2) * 4;
+    char* slab = nullptr;
+    NMPC_HIP_CHECK(hipMalloc((void**)&slab, bytes));
+    hipError_t e0 = hipMemsetAsync(slab, 0, bytes, s);
+    if (e0 != hipSuccess) { (void)hipFree(slab); set_error("nmpc_target_select: memset failed"); return 1; }
+    char* p = slab;
+    a.xs = (double*)p; p += nB * nx * 8; a.us = (double*)p; p += nB * 8;
+    a.xs32 = (float*)p; p += nB * nx * 4; a.us32 = (float*)p; p += nB * 4;
+    a.A32 = (float*)p; p += nB * nx * nx * 4; a.B32 = (float*)p; p += nB * nx * 4; a.C32 = (float*)p; p += nB * nx * 4;
+    a.act = (int*)p; p += 2 * nB * 4; a.counts = (int*)p;
+    int rc = 0;
+    if (hipMemsetAsync(status, 0, nB * 4, s) != hipSuccess) { (void)hipFree(slab); set_error("nmpc_target_select: memset failed"); return 1; }
+    const int threads = 64, grid = (nb + threads - 1) / threads;
+    for (int j = 0; j < nsamp && !rc; ++j) {
+        if (hipMemsetAsync(a.counts, 0, (max_lpv + 1) * 4, s) != hipSuccess) { rc = 1; break; }
+        for (int i = 0; i < max_lpv && !rc; ++i) {
+            EmbedArgs ea{};
+            ea.x = a.xs32; ea.u = a.us32; ea.xc = a.xs32; ea.A = a.A32; ea.B = a.B32; ea.C = a.C32;
+            ea.npts = nb; ea.group = 1;
+            if (i > 0) { ea.count_dev = a.counts + i; ea.act = a.act + (size_t)(i & 1) * nb; }
+            rc = embed_launch(m->d, ea, nt, s);
+            if (rc) break;
+            if (nx == 2) hipLaunchKernelGGL((target_kernel<2>), dim3(grid), dim3(threads), 0, s, a, j, i);
+            else if (nx == 3) hipLaunchKernelGGL((target_kernel<3>), dim3(grid), dim3(threads), 0, s, a, j, i);
+            else { set_error("nmpc_target_select: nx=%d unsupported", nx); rc = 1; }
+        }
+    }
+    hipError_t e1 = hipStreamSynchronize(s);
+    hipError_t e2 = hipGetLastError();
+    (void)hipFree(slab);
+    if (rc) return 1;
+    NMPC_REQUIRE(e1 == hipSuccess && e2 == hipSuccess, "nmpc_target_select: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+    return 0;
+}

@@ -173,8 +173,9 @@ def output_NMPC_linear(system, encoder, u_min, u_max, y_min, y_max, x0, Q, R, dt
     lam, w = quad_nodes("simpson", stages)                                # lambda_simpson, NMPC_test.py:59
     if targets is None:
         from .target import getXsUs_Cs
+        from .target import GetABC
         Xs, Us, _ = getXsUs_Cs(y_ref_n[:, :Nsim + Nc].to(dev), nx, nu, ny, Nsim + Nc, umin_n, umax_n, [ymin_n],
-                               [ymax_n], encoder, lam, w)
+                               [ymax_n], GetABC(encoder, lam, w))
     else:
         Xs, Us = (_f64(t, dev) for t in targets)
         Xs = Xs.reshape(B, nx, -1)[:, :, :Nsim + Nc]; Us = Us.reshape(B, nu, -1)[:, :, :Nsim + Nc]

@@ -1,0 +1,57 @@
+"""Steady-state target selector with the reference's signature (mpcUtil.py:241-320 getXsUs_Cs),
+batched over controllers on the GPU."""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check, ptr, current_stream
+from .mpcutil import _f64
+
+
+class GetABC:
+    """Handle standing for the reference's CasADi functions get_A / get_B / get_C
+    (NMPC_test.py:60-62): the model plus the quadrature node table they were built with."""
+
+    def __init__(self, model, lam, w):
+        self.model = model
+        self.lam = np.ascontiguousarray(lam, np.float32)
+        self.w = np.ascontiguousarray(w, np.float32)
+
+
+def getXsUs_Cs(y_reference_list_normalize, nx, nu, ny, Nsim, u_min, u_max, y_min, y_max, get_A, get_B=None,
+               get_C=None, f0=None, h0=None, *, max_lpv=20, tol=1e-4, return_iters=False):
+    """y_reference_list_normalize [B, >= Nsim] (or 1-D).  get_A: a GetABC handle, or the model
+    itself followed by (lam, w) in get_B / get_C.  f0 / h0 are accepted for signature
+    compatibility; the model's own offsets f(0,0), h(0) are used.
+    Returns (Xs [B, nx, Nsim], Us [B, nu, Nsim], Es [B, 1, Nsim]) as the reference lays them out."""
+    if not isinstance(get_A, GetABC):
+        get_A = GetABC(get_A, get_B, get_C)
+    model = get_A.model
+    assert (nx, nu, ny) == (model.nx, model.nu, model.ny)
+    dev = model.device
+    yr = _f64(y_reference_list_normalize, dev)
+    single = yr.dim() == 1
+    if single:
+        yr = yr[None]
+    yr = yr[:, :Nsim].contiguous()
+    B = yr.shape[0]
+    Xs = torch.empty(B, Nsim, nx, dtype=torch.float64, device=dev)
+    Us = torch.empty(B, Nsim, dtype=torch.float64, device=dev)
+    Es = torch.empty(B, Nsim, dtype=torch.float64, device=dev)
+    iters = torch.zeros(B, Nsim, dtype=torch.int32, device=dev)
+    status = torch.zeros(B, dtype=torch.int32, device=dev)
+    sc = lambda v: float(np.asarray(v, np.float64).reshape(-1)[0])
+    with torch.cuda.device(dev):
+        rc = lib().nmpc_target_select(model.handle, B, Nsim, ptr(yr), sc(u_min), sc(u_max), sc(y_min), sc(y_max),
+                                      get_A.lam.ctypes.data_as(_lib.c_float_p), get_A.w.ctypes.data_as(_lib.c_float_p),
+                                      get_A.lam.size, int(max_lpv), float(tol), ptr(Xs), ptr(Us), ptr(Es), ptr(iters),
+                                      ptr(status), current_stream())
+    check(rc, "nmpc_target_select")
+    if int(status.sum()):
+        raise _lib.NmpcError("getXsUs_Cs: singular steady-state system for %d controllers" % int((status != 0).sum()))
+    out = (Xs.transpose(1, 2).contiguous(), Us[:, None, :].contiguous(), Es[:, None, :].contiguous())
+    if single:
+        out = tuple(o[0] for o in out)
+    if return_iters:
+        return out + (iters[0] if single else iters,)
+    return out
