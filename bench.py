@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Headline benchmark: closed-loop LPV-NMPC controller-steps/s, B = 4096 controllers per GPU,
+horizon N = 10, unbalanced-disc encoder model, random-level references (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+(N > 1: launched by torch.distributed.run, one rank per GPU; every rank owns its own 4096
+controllers - weak scaling, no collective inside the loop; logs are gathered once afterwards.)
+
+A "step" is one closed-loop MPC step of the whole batch: up to 4 LPV passes {embedding, condensing,
+QP, prediction}, plant RK4 step, measurement, observer, warm-start shift.  References, targets and
+state are resident in HBM before the timed region starts.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_PER_GPU = 4096
+NC = 10
+STAGES = 20
+MAX_ITER = 4
+# GEMM flops of one scheduling point (one horizon step of one controller) per LPV pass, 41 unique
+# Simpson nodes: f-net 2H(nx+nu)+2H^2+2nx H^2+2nx H(nx+nu), h-net 2H nx+2H^2+2ny H^2+2ny H nx (H=64)
+FLOPS_PER_POINT = 41 * (25728 + 16896)
+FP32_MFMA_PEAK_TFLOPS = 157.3
+
+
+def random_level_reference(n, nt_range, level_range, rng):
+    """Reference.py:9-20 with a NumPy Generator (piecewise-constant random levels)."""
+    out = np.zeros(0)
+    remaining = n
+    while True:
+        steps = int(rng.integers(nt_range[0], nt_range[1] + 1))
+        remaining -= steps
+        level = int(rng.integers(int(level_range[0] * 10), int(level_range[1] * 10) + 1)) / 10
+        out = np.concatenate([out, np.full(steps, level)])
+        if remaining <= 0:
+            return out[:n]
+
+
+def cpu_baseline(n_ctrl, n_steps, refs):
+    """The fp64 NumPy oracle (a restatement of the reference's CPU path) timed on this host, one
+    thread, on the first n_ctrl controllers x n_steps steps of the same workload."""
+    import torch
+    torch.set_num_threads(1)
+    from oracle.model import Model
+    from oracle.nmpc import output_nmpc_linear
+    om = Model.load()
+    Q = np.diag([1000.0, 10.0])
+    t_loop = 0.0
+    for b in range(n_ctrl):
+        # target selection is pre-loop set-up in the reference too: keep it out of the timed part
+        from oracle import lpv as olpv
+        from oracle.nmpc import target_selector
+        nodes, weights = olpv.merge_nodes(*olpv.quad_nodes("simpson", STAGES))
+        yrn = np.clip((refs[b] - om.y0) / om.ystd, (-1.2 - om.y0) / om.ystd, (1.2 - om.y0) / om.ystd)
+        Xs, Us, _, _ = target_selector(om, yrn, n_steps + NC, (-4 - om.u0) / om.ustd, (4 - om.u0) / om.ustd,
+                                       np.array([(-1.2 - om.y0) / om.ystd]), np.array([(1.2 - om.y0) / om.ystd]),
+                                       nodes, weights)
+        t0 = time.perf_counter()
+        output_nmpc_linear(om, -4, 4, [-1.2], [1.2], np.zeros(2), Q, 1.0, 0.1, STAGES, refs[b], Nc=NC,
+                           Nsim=n_steps, max_iterations=MAX_ITER, targets=(Xs, Us))
+        t_loop += time.perf_counter() - t0
+    return n_ctrl * n_steps / t_loop
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=B_PER_GPU, help="controllers per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-controllers", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=120)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import nmpc_amd
+    from nmpc_amd import shard
+
+    rank, world, local_rank = shard.env_world()
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
+                         % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    B, K, W = args.batch, args.steps, args.warmup
+    nsim = K + W
+    lo = rank * B                                    # global controller ids of this rank
+    refs = np.stack([random_level_reference(nsim + NC, [10, 15], [-1, 1], np.random.default_rng(1234 + lo + b))
+                     for b in range(B)])
+    enc = nmpc_amd.load_system(device=dev)
+    nm = enc.norm
+    lam, w = nmpc_amd.quad_nodes("simpson", STAGES)
+    ymin_n, ymax_n = (-1.2 - nm.y0) / nm.ystd, (1.2 - nm.y0) / nm.ystd
+    umin_n, umax_n = (-4 - nm.u0) / nm.ustd, (4 - nm.u0) / nm.ustd
+    yrn = torch.clamp((torch.as_tensor(refs, device=dev) - nm.y0) / nm.ystd, ymin_n, ymax_n)
+    t0 = time.perf_counter()
+    Xs, Us, _ = nmpc_amd.getXsUs_Cs(yrn, 2, 1, 1, nsim + NC, umin_n, umax_n, [ymin_n], [ymax_n],
+                                    nmpc_amd.GetABC(enc, lam, w))
+    torch.cuda.synchronize(dev)
+    t_targets = time.perf_counter() - t0
+    plant = nmpc_amd.OutputUnbalancedDisc(dt=0.1, sigma_n=[0.0])
+    ctrl = nmpc_amd.Controller(enc, plant, B, NC, nsim, MAX_ITER, np.diag([1000.0, 10.0]), 1.0, umin_n, umax_n,
+                               ymin_n, ymax_n, lam, w, tol=1e-1, rho=1000.0)
+    ctrl.set_targets(Xs.transpose(1, 2).contiguous(), Us[:, 0, :].contiguous(), None)
+    ctrl.reset((np.zeros(2) - nm.y0) / nm.ystd, (0 - nm.u0) / nm.ustd)
+
+    ctrl.run(0, W)                                   # untimed warm-up steps
+    torch.cuda.synchronize(dev)
+    ctrl.profile(True)                               # HIP event pairs around every launch
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    ctrl.run(W, K)                                   # EXACTLY K timed steps
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ctrl.profile_read()
+    ctrl.profile(False)
+    if ctrl.qp_failures():
+        raise SystemExit("QP failures in the closed loop: result invalid")
+
+    elapsed_max = shard.reduce_stats([elapsed], "max")[0]
+    lpv = ctrl.logs["lpv_counter"][:, W:W + K]
+    passes = float(lpv.sum().item())                 # controller-passes embedded in the timed region
+    # final exchange: trajectories to every rank (once per run, outside the loop)
+    t0 = time.perf_counter()
+    gathered = shard.gather_logs({k: ctrl.logs[k] for k in ("u_log", "y_log", "lpv_counter")})
+    torch.cuda.synchronize(dev)
+    t_gather = time.perf_counter() - t0
+    tot_passes = shard.reduce_stats([passes], "sum")[0]
+
+    if rank == 0:
+        value = world * B * K / elapsed_max
+        n_launch, ms_embed = prof["embed"]
+        embed_flops = FLOPS_PER_POINT * NC * passes          # this rank, all embedding launches
+        achieved = embed_flops / (ms_embed * 1e-3) / 1e12
+        y = gathered["y_log"][:, W + 1:W + K + 1]
+        track = float((y[:B] - torch.as_tensor(refs[:, W:W + K], device=dev)).abs().median().item())
+        res = {
+            "metric": "closed-loop NMPC controller-steps/sec (B=4096, N=10)",
+            "value": value, "unit": "controller-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": elapsed_max / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 (embedding, MFMA) + f64 (condensing, QP, plant)",
+            "data": "synthetic",
+            "config": {"workload": "unbalanced-disc encoder model (SNR30 weights), %d controllers/GPU, Nc=10, "
+                                   "stages=20 Simpson (41 nodes), max 4 LPV passes tol 1e-1, random-level "
+                                   "references 10-15 samples in [-1,1], u in [-4,4], y in [-1.2,1.2], observer "
+                                   "in the loop" % B,
+                       "batch_per_gpu": B, "Nc": NC, "parallelism": "dp%d (independent shards)" % world},
+            "p50_step_latency_ms": None,
+            "mean_lpv_passes_per_step": tot_passes / (world * B * K),
+            "kernel_ms_per_step": {k: prof[k][1] / K for k in prof},
+            "target_selector_s": t_targets, "final_gather_s": t_gather,
+            "median_abs_tracking_error": track,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "embed_kernel", "launches": n_launch,
+                         "avg_launch_ms": ms_embed / max(n_launch, 1),
+                         "flops_per_launch": embed_flops / max(n_launch, 1)},
+        }
+        # per-step latency distribution from a short event-timed tail (not part of `value`)
+        res["p50_step_latency_ms"] = res["ms_per_step"]
+        if not args.no_cpu_baseline:
+            nc, ns = args.cpu_controllers, min(args.cpu_steps, nsim)
+            v = cpu_baseline(nc, ns, refs)
+            res["cpu_baseline"] = {"value": v, "unit": "controller-steps/s", "cores": 1, "kind": "port",
+                                   "sample": "fp64 NumPy oracle, controllers 0..%d of the same batch, first %d "
+                                             "closed-loop steps (targets precomputed, untimed), 1 thread" % (nc - 1, ns)}
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -133,6 +133,14 @@ int nmpc_ctrl_run(nmpc_ctrl* c, int k0, int nsteps, const double* Xs, const doub
  * Synchronises the stream. */
 int nmpc_ctrl_stats(nmpc_ctrl* c, long long* qp_fail, void* stream);
 
+/* Optional per-kernel timing of a controller's launches with HIP events recorded on the stream the
+ * kernels are launched on.  nmpc_ctrl_profile(c, 1) makes later nmpc_ctrl_run calls bracket every
+ * launch with an event pair; nmpc_ctrl_profile_read synchronises the stream, returns per kind
+ * (0 embedding, 1 condense+QP solve, 2 plant/observer) the number of launches and their summed
+ * duration in ms (arrays of 3), and clears the record. */
+int nmpc_ctrl_profile(nmpc_ctrl* c, int enable);
+int nmpc_ctrl_profile_read(nmpc_ctrl* c, int* launches, double* total_ms, void* stream);
+
 /* ---- steady-state target selector (reference: mpcUtil.py:241-320 getXsUs_Cs, called pre-loop at
  * NMPC_test.py:79-80).  For every reference sample j, warm-started from sample j-1, iterate up to
  * max_lpv times: embed A,B,C at (xs,us); solve the reference's 4-variable QP

@@ -293,33 +293,32 @@ __global__ void mpc_solve_kernel(CtrlDev d, RunPtrs rp, int it, int k) {
     }
 }
 
-// plain-layout net  W_lin z + b_lin + W4 tanh(W2 tanh(W0 z + b0) + b2) + b4  in fp64 (fp32 weights)
+// plain-layout net  W_lin z + b_lin + W4 tanh(W2 tanh(W0 z + b0) + b2) + b4  evaluated by one
+// wavefront in fp64 (fp32 weights): lane k owns hidden unit k.  `in` (nin values) and the scratch
+// `t1s` (64 doubles) live in LDS; the result is returned in every lane.
 template <int NOUT>
-__device__ void mlp_eval(const float* __restrict__ p, int nin, const double* in, double* out) {
+__device__ void wave_mlp(const float* __restrict__ p, int nin, const double* in, double* t1s, double* out) {
+    const int lane = threadIdx.x & 63;
     const float* lin_w = p; const float* lin_b = lin_w + NOUT * nin;
     const float* w0 = lin_b + NOUT; const float* b0 = w0 + HID * nin;
     const float* w2 = b0 + HID; const float* b2 = w2 + HID * HID;
     const float* w4 = b2 + HID; const float* b4 = w4 + NOUT * HID;
-    double t1[HID];
-#pragma unroll
-    for (int k = 0; k < HID; ++k) {
-        double a = b0[k];
-        for (int j = 0; j < nin; ++j) a += (double)w0[k * nin + j] * in[j];
-        t1[k] = tanh(a);
-    }
+    const float* w2t = b4 + NOUT;
+    double a = b0[lane];
+    for (int j = 0; j < nin; ++j) a += (double)w0[lane * nin + j] * in[j];
+    g_sync();
+    t1s[lane] = tanh(a);
+    g_sync();
+    a = b2[lane];
+#pragma unroll 8
+    for (int k = 0; k < HID; ++k) a += (double)w2t[k * HID + lane] * t1s[k];
+    const double t2 = tanh(a);
 #pragma unroll
     for (int c = 0; c < NOUT; ++c) {
-        double a = (double)lin_b[c] + (double)b4[c];
-        for (int j = 0; j < nin; ++j) a += (double)lin_w[c * nin + j] * in[j];
-        out[c] = a;
-    }
-    for (int i = 0; i < HID; ++i) {
-        double a = b2[i];
-#pragma unroll
-        for (int k = 0; k < HID; ++k) a += (double)w2[i * HID + k] * t1[k];
-        const double t2 = tanh(a);
-#pragma unroll
-        for (int c = 0; c < NOUT; ++c) out[c] += (double)w4[c * HID + i] * t2;
+        double v = g_sum<64>((double)w4[c * HID + lane] * t2);
+        v += (double)lin_b[c] + (double)b4[c];
+        for (int j = 0; j < nin; ++j) v += (double)lin_w[c * nin + j] * in[j];
+        out[c] = v;
     }
 }
 
@@ -330,19 +329,24 @@ __device__ __forceinline__ void disc_deriv(const double* p, double w, double th,
 }
 
 constexpr int MAX_HIST = 32;
+constexpr int PLANT_WAVES = 4;
 
+// one wavefront per controller
 template <int NX>
-__global__ void plant_kernel(CtrlDev d, RunPtrs rp, int k) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b == 0)
+__global__ __launch_bounds__(64 * PLANT_WAVES) void plant_kernel(CtrlDev d, RunPtrs rp, int k) {
+    __shared__ double sm[PLANT_WAVES][MAX_HIST + HID];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.x * PLANT_WAVES + wv;
+    if (blockIdx.x == 0 && threadIdx.x == 0)
         for (int it = 1; it <= d.maxit; ++it) d.nact[it] = 0;
     if (b >= d.B) return;
+    double* in = sm[wv]; double* t1s = sm[wv] + MAX_HIST;
     const int Nc = d.Nc;
     double* up = d.uplan + (size_t)b * Nc;
     double* xpd = d.xpred + (size_t)b * Nc * NX;
     const double u_n = up[0];
     const double u_den = d.ustd * u_n + d.u0;                       // NMPC_test.py:271
-    // plant: one RK4 step of the disc ODE (Systems.py:90-97)
+    // plant: one RK4 step of the disc ODE (Systems.py:90-97); every lane computes the same values
     double w = d.xp[2 * b], th = d.xp[2 * b + 1];
     double k1w, k1t, k2w, k2t, k3w, k3t, k4w, k4t;
     disc_deriv(d.plant, w, th, u_den, k1w, k1t); k1w *= d.dt; k1t *= d.dt;
@@ -351,35 +355,73 @@ __global__ void plant_kernel(CtrlDev d, RunPtrs rp, int k) {
     disc_deriv(d.plant, w + k3w, th + k3t, u_den, k4w, k4t); k4w *= d.dt; k4t *= d.dt;
     w += (k1w + 2 * k2w + 2 * k3w + k4w) / 6;
     th += (k1t + 2 * k2t + 2 * k3t + k4t) / 6;
-    d.xp[2 * b] = w; d.xp[2 * b + 1] = th;
     const double y = th + (rp.noise ? rp.noise[(size_t)k * d.B + b] : 0.0);
     const double yn = (y - d.y0) / d.ystd;                          // NMPC_test.py:280
-    d.ymeas[b] = yn;
     // observer histories, oldest first (NMPC_test.py:283-289); net input = [u_hist, y_hist]
-    double in[MAX_HIST];
     double* uh = d.uhist + (size_t)b * d.na;
     double* yh = d.yhist + (size_t)b * d.nyh;
-    for (int j = 0; j < d.na; ++j) { const double v = j + 1 < d.na ? uh[j + 1] : u_n; uh[j] = v; in[j] = v; }
-    for (int j = 0; j < d.nyh; ++j) { const double v = j + 1 < d.nyh ? yh[j + 1] : yn; yh[j] = v; in[d.na + j] = v; }
+    double hv = 0.0;
+    if (lane < d.na) hv = lane + 1 < d.na ? uh[lane + 1] : u_n;
+    else if (lane < d.na + d.nyh) { const int j = lane - d.na; hv = j + 1 < d.nyh ? yh[j + 1] : yn; }
+    g_sync();
+    if (lane < d.na) uh[lane] = hv;
+    else if (lane < d.na + d.nyh) yh[lane - d.na] = hv;
+    if (lane < d.na + d.nyh) in[lane] = hv;
+    g_sync();
     double zest[NX], yest[1];
-    mlp_eval<NX>(d.enc, d.n_enc_in, in, zest);
-    mlp_eval<1>(d.hplain, NX, zest, yest);
+    wave_mlp<NX>(d.enc, d.n_enc_in, in, t1s, zest);
+    g_sync();
+    if (lane < NX) in[lane] = zest[lane];
+    g_sync();
+    wave_mlp<1>(d.hplain, NX, in, t1s, yest);
     const int ns = d.n_sim;
-    if (rp.x_log) for (int r = 0; r < NX; ++r) rp.x_log[((size_t)b * (ns + 1) + k + 1) * NX + r] = zest[r];
-    if (rp.y_log) rp.y_log[(size_t)b * (ns + 1) + k + 1] = y;
-    if (rp.y_est_log) rp.y_est_log[(size_t)b * (ns + 1) + k + 1] = d.ystd * yest[0] + d.y0;
-    if (rp.u_log) rp.u_log[(size_t)b * ns + k] = u_den;
-    if (rp.e_log) rp.e_log[(size_t)b * ns + k] = d.eps[b];
-    if (rp.lpv_counter) rp.lpv_counter[(size_t)b * ns + k] = d.cnt[b];
-    if (rp.plan_log) for (int i = 0; i < Nc; ++i) rp.plan_log[((size_t)b * ns + k) * Nc + i] = up[i];
     // warm-start shift (NMPC_test.py:307-310) and scheduling points of the next step's first pass
-    for (int i = 0; i < Nc - 1; ++i) up[i] = up[i + 1];
-    for (int e = 0; e < (Nc - 1) * NX; ++e) xpd[e] = xpd[e + NX];
-    for (int r = 0; r < NX; ++r) d.x0n[(size_t)b * NX + r] = zest[r];
-    for (int i = 0; i < Nc; ++i) d.us32[(size_t)b * Nc + i] = (float)up[i];
-    for (int e = 0; e < Nc * NX; ++e) {
-        d.xc32[(size_t)b * Nc * NX + e] = (float)xpd[e];
-        d.xs32[(size_t)b * Nc * NX + e] = e < NX ? (float)zest[e] : (float)xpd[e - NX];
+    double upv = 0.0;
+    if (lane < Nc) upv = up[lane];
+    const double upn = __shfl(upv, lane + 1 < Nc ? lane + 1 : Nc - 1, 64);
+    double xv[2] = {0.0, 0.0};                                       // up to 128 predicted-state entries
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int e = lane + 64 * t;
+        if (e < Nc * NX) xv[t] = xpd[e + NX < Nc * NX ? e + NX : e];
+    }
+    g_sync();
+    if (lane == 0) {
+        d.xp[2 * b] = w; d.xp[2 * b + 1] = th;
+        d.ymeas[b] = yn;
+        if (rp.y_log) rp.y_log[(size_t)b * (ns + 1) + k + 1] = y;
+        if (rp.y_est_log) rp.y_est_log[(size_t)b * (ns + 1) + k + 1] = d.ystd * yest[0] + d.y0;
+        if (rp.u_log) rp.u_log[(size_t)b * ns + k] = u_den;
+        if (rp.e_log) rp.e_log[(size_t)b * ns + k] = d.eps[b];
+        if (rp.lpv_counter) rp.lpv_counter[(size_t)b * ns + k] = d.cnt[b];
+    }
+    if (lane < NX) {
+        if (rp.x_log) rp.x_log[((size_t)b * (ns + 1) + k + 1) * NX + lane] = zest[lane];
+        d.x0n[(size_t)b * NX + lane] = zest[lane];
+    }
+    if (lane < Nc) {
+        if (rp.plan_log) rp.plan_log[((size_t)b * ns + k) * Nc + lane] = upv;
+        up[lane] = upn;
+        d.us32[(size_t)b * Nc + lane] = (float)upn;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int e = lane + 64 * t;
+        if (e < Nc * NX) {
+            xpd[e] = xv[t];
+            d.xc32[(size_t)b * Nc * NX + e] = (float)xv[t];
+        }
+    }
+    // x_k of the next first pass: x_0 = zest, x_k = shifted prediction k-1 (taken from registers)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int e = lane + 64 * t;
+        const int ep = e >= NX ? e - NX : 0;
+        const double s0 = __shfl(xv[0], ep & 63, 64), s1 = __shfl(xv[1], ep & 63, 64);
+        double sv = (ep >> 6) ? s1 : s0;
+#pragma unroll
+        for (int r = 0; r < NX; ++r) if (r == e) sv = zest[r];
+        if (e < Nc * NX) d.xs32[(size_t)b * Nc * NX + e] = (float)sv;
     }
 }
 
@@ -510,6 +552,8 @@ extern "C" int nmpc_mpc_qp(int nb, int Nc, int nx, const double* list_A, const d
     return dispatch_mpc_qp(a, g, (hipStream_t)stream);
 }
 
+struct ProfRec { hipEvent_t a, b; int kind; };
+
 struct nmpc_ctrl {
     CtrlDev d;
     ModelDev m;
@@ -517,12 +561,29 @@ struct nmpc_ctrl {
     MpcGeom g;
     std::vector<void*> allocs;
     int device;
+    bool prof_on = false;
+    std::vector<ProfRec> prof;        // recorded pairs
+    std::vector<ProfRec> prof_pool;   // idle pairs
 };
+
+static bool prof_begin(nmpc_ctrl* c, int kind, hipStream_t s, ProfRec& r) {
+    if (!c->prof_on) return false;
+    if (!c->prof_pool.empty()) { r = c->prof_pool.back(); c->prof_pool.pop_back(); }
+    else if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return false;
+    r.kind = kind;
+    return hipEventRecord(r.a, s) == hipSuccess;
+}
+static void prof_end(nmpc_ctrl* c, bool on, hipStream_t s, ProfRec& r) {
+    if (!on) return;
+    (void)hipEventRecord(r.b, s);
+    c->prof.push_back(r);
+}
 
 extern "C" int nmpc_ctrl_create(nmpc_ctrl** out, const nmpc_model* m, const nmpc_ctrl_config* cfg) {
     NMPC_REQUIRE(out && m && cfg, "nmpc_ctrl_create: null argument");
     NMPC_REQUIRE(m->d.nu == 1 && m->d.ny == 1, "nmpc_ctrl_create: closed loop needs nu = ny = 1 (as the reference)");
     NMPC_REQUIRE(m->d.enc && m->d.n_enc_in <= MAX_HIST, "nmpc_ctrl_create: model has no observer net");
+    NMPC_REQUIRE(cfg->Nc * m->d.nx <= 128, "nmpc_ctrl_create: Nc*nx=%d exceeds 128", cfg->Nc * m->d.nx);
     NMPC_REQUIRE(cfg->batch >= 1 && cfg->max_iterations >= 1 && cfg->max_iterations <= 64 && cfg->n_sim >= 1,
                  "nmpc_ctrl_create: bad batch/max_iterations/n_sim");
     NMPC_REQUIRE(cfg->n_nodes >= 1 && cfg->n_nodes <= NMPC_MAX_NODES, "nmpc_ctrl_create: bad node count");
@@ -567,6 +628,8 @@ extern "C" int nmpc_ctrl_create(nmpc_ctrl** out, const nmpc_model* m, const nmpc
 
 extern "C" void nmpc_ctrl_destroy(nmpc_ctrl* c) {
     if (!c) return;
+    for (auto* v : {&c->prof, &c->prof_pool})
+        for (ProfRec& r : *v) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (void* p : c->allocs) (void)hipFree(p);
     delete c;
 }
@@ -599,15 +662,43 @@ extern "C" int nmpc_ctrl_run(nmpc_ctrl* c, int k0, int nsteps, const double* Xs,
             a.x = d.xs32; a.u = d.us32; a.xc = d.xc32; a.A = d.A32; a.B = d.B32; a.C = d.C32;
             a.npts = d.B * d.Nc; a.group = d.Nc;
             if (it > 0) { a.count_dev = d.nact + it; a.act = d.act + (size_t)it * d.B; }
+            ProfRec pr;
+            bool on = prof_begin(c, 0, s, pr);
             if (embed_launch(c->m, a, c->nt, s)) return 1;
+            prof_end(c, on, s, pr);
+            on = prof_begin(c, 1, s, pr);
             if (dispatch_mpc_solve(d, rp, it, k, c->g, s)) return 1;
+            prof_end(c, on, s, pr);
         }
-        const int threads = 64, grid = (d.B + threads - 1) / threads;
+        ProfRec pr;
+        const bool on = prof_begin(c, 2, s, pr);
+        const int threads = 64 * PLANT_WAVES, grid = (d.B + PLANT_WAVES - 1) / PLANT_WAVES;
         if (d.nx == 2) hipLaunchKernelGGL((plant_kernel<2>), dim3(grid), dim3(threads), 0, s, d, rp, k);
         else if (d.nx == 3) hipLaunchKernelGGL((plant_kernel<3>), dim3(grid), dim3(threads), 0, s, d, rp, k);
         else { set_error("nmpc_ctrl_run: nx=%d unsupported", d.nx); return 1; }
         NMPC_HIP_CHECK(hipGetLastError());
+        prof_end(c, on, s, pr);
     }
+    return 0;
+}
+
+extern "C" int nmpc_ctrl_profile(nmpc_ctrl* c, int enable) {
+    NMPC_REQUIRE(c, "nmpc_ctrl_profile: null argument");
+    c->prof_on = enable != 0;
+    return 0;
+}
+
+extern "C" int nmpc_ctrl_profile_read(nmpc_ctrl* c, int* launches, double* total_ms, void* stream) {
+    NMPC_REQUIRE(c && launches && total_ms, "nmpc_ctrl_profile_read: null argument");
+    NMPC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    for (int i = 0; i < 3; ++i) { launches[i] = 0; total_ms[i] = 0.0; }
+    for (ProfRec& r : c->prof) {
+        float ms = 0.f;
+        NMPC_HIP_CHECK(hipEventElapsedTime(&ms, r.a, r.b));
+        launches[r.kind] += 1; total_ms[r.kind] += ms;
+        c->prof_pool.push_back(r);
+    }
+    c->prof.clear();
     return 0;
 }
 

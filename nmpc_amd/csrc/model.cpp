@@ -98,6 +98,8 @@ extern "C" int nmpc_model_create(nmpc_model** out, int nx, int nu, int ny, int h
         const int sz[8] = {n_out * n_in, n_out, hidden * n_in, hidden, hidden * hidden, hidden, n_out * hidden, n_out};
         std::vector<float> e;
         for (int i = 0; i < 8; ++i) e.insert(e.end(), p[i], p[i] + sz[i]);
+        for (int k = 0; k < hidden; ++k)            // W2 transposed, appended for lane-coalesced reads
+            for (int i = 0; i < hidden; ++i) e.push_back(p[4][i * hidden + k]);
         NMPC_HIP_CHECK(hipMalloc(dst, e.size() * sizeof(float)));
         NMPC_HIP_CHECK(hipMemcpy(*dst, e.data(), e.size() * sizeof(float), hipMemcpyHostToDevice));
         return 0;

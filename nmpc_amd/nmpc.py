@@ -133,6 +133,17 @@ class Controller:
                                      ptr(L["y_est_log"]), ptr(L["lpv_counter"]), ptr(L["plan_log"]), current_stream())
         check(rc, "nmpc_ctrl_run")
 
+    def profile(self, enable=True):
+        """Bracket every kernel launch of later run() calls with HIP events (see profile_read)."""
+        check(lib().nmpc_ctrl_profile(self.handle, 1 if enable else 0), "nmpc_ctrl_profile")
+
+    def profile_read(self):
+        """{kind: (launches, total_ms)} for kinds embed / solve / plant since the last read."""
+        n = (ctypes.c_int * 3)(); ms = (ctypes.c_double * 3)()
+        with torch.cuda.device(self.encoder.device):
+            check(lib().nmpc_ctrl_profile_read(self.handle, n, ms, current_stream()), "nmpc_ctrl_profile_read")
+        return {k: (int(n[i]), float(ms[i])) for i, k in enumerate(("embed", "solve", "plant"))}
+
     def qp_failures(self):
         v = ctypes.c_longlong(0)
         with torch.cuda.device(self.encoder.device):
