@@ -7,3 +7,4 @@ from .mpcutil import getPhi, getGamma, getF0, getZ, getPsi, getOmega, getDEMc, g
 from .qp import solve_qp  # noqa: F401
 from .nmpc import OutputUnbalancedDisc, Controller, mpc_qp, output_NMPC_linear  # noqa: F401
 from .target import GetABC, getXsUs_Cs  # noqa: F401
+from .lpvrk4 import lpv_rk4  # noqa: F401

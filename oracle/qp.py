@@ -31,12 +31,14 @@ def _solve_ineq(P, q, G, h, tol, max_iter):
     gnorm = np.maximum(np.linalg.norm(G, axis=1), 1e-300)
     scale = 1.0 + np.abs(h)
     it = 0
+    if m == 0:
+        return x, np.zeros(0), 0
     while True:
         s = h - G @ x
         viol = s / gnorm
         viol[W] = 0.0
         p = int(np.argmin(viol))
-        if m == 0 or s[p] >= -tol * scale[p]:
+        if s[p] >= -tol * scale[p]:
             out = np.zeros(m)
             out[W] = lam
             return x, out, it

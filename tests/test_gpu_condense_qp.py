@@ -1,0 +1,143 @@
+"""GPU parity tests of condensing (nmpc_condense), lpv_rk4, the batched QP (nmpc_qp_solve) and
+the condensed MPC QP (nmpc_mpc_qp) through the C ABI.  fp64 kernels: bar 1e-9 or tighter."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lpv as olpv, mpcutil as omu
+from oracle.qp import solve_qp as osolve, kkt_residual
+from oracle.nmpc import mpc_qp as omq
+from conftest import disc_setup
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a) - b).max() / max(1.0, np.abs(b).max()))
+
+
+def test_condense_golden(golden):
+    import nmpc_amd
+    g = golden["condense"]
+    for ci, (Nc, nx, nu, ny) in enumerate(g["cases"]):
+        k = "c%d_" % ci
+        lA, lB, lC, f0 = g[k + "list_A"], g[k + "list_B"], g[k + "list_C"], g[k + "f0"]
+        assert rel(nmpc_amd.getPhi(lA, Nc, nx, nu).cpu().numpy(), g[k + "Phi"]) < 1e-13
+        assert rel(nmpc_amd.getGamma(lA, lB, Nc, nx, nu).cpu().numpy(), g[k + "Gamma"]) < 1e-13
+        assert rel(nmpc_amd.getF0(lA, f0, Nc, nx).cpu().numpy(), g[k + "F0"]) < 1e-13
+        assert np.array_equal(nmpc_amd.getZ(lC, Nc, ny, nx).cpu().numpy(), g[k + "Z"])
+        assert np.array_equal(nmpc_amd.getPsi(Nc, g[k + "R"]).cpu().numpy(), g[k + "Psi"])
+        assert np.array_equal(nmpc_amd.getOmega(Nc, g[k + "Q"]).cpu().numpy(), g[k + "Omega"])
+        b = g[k + "bounds"]
+        lo, hi, ylo, yhi = b[:nx], b[nx:2 * nx], b[2 * nx:2 * nx + ny], b[2 * nx + ny:2 * nx + 2 * ny]
+        for nm, v in zip("DEMc", nmpc_amd.getDEMc(lo, hi, b[-2], b[-1], Nc, nx, nu)):
+            assert np.array_equal(v.cpu().numpy(), g[k + "st_" + nm]), nm
+        for nm, v in zip("DEMc", nmpc_amd.getDEMc_out(ylo, yhi, b[-2], b[-1], Nc, ny, nu)):
+            assert np.array_equal(v.cpu().numpy(), g[k + "out_" + nm]), nm
+
+
+def test_condense_batched_and_ragged():
+    import nmpc_amd
+    rng = np.random.default_rng(0)
+    for batch, Nc, nx in (((3, 5), 6, 2), ((1,), 1, 3), ((257,), 10, 2)):
+        lA = rng.uniform(-1, 1, batch + (Nc * nx, nx)); lB = rng.uniform(-1, 1, batch + (Nc * nx, 1)); f0 = rng.uniform(-1, 1, nx)
+        Phi = nmpc_amd.getPhi(lA, Nc, nx, 1).cpu().numpy(); Gam = nmpc_amd.getGamma(lA, lB, Nc, nx, 1).cpu().numpy()
+        F0 = nmpc_amd.getF0(lA, f0, Nc, nx).cpu().numpy()
+        flat = lambda a: a.reshape((-1,) + a.shape[len(batch):])
+        for i in range(0, flat(lA).shape[0], 37):
+            assert rel(flat(Phi)[i], omu.getPhi(flat(lA)[i], Nc, nx)) < 1e-13
+            assert rel(flat(Gam)[i], omu.getGamma(flat(lA)[i], flat(lB)[i], Nc, nx, 1)) < 1e-13
+            assert rel(flat(F0)[i], omu.getF0(flat(lA)[i], f0, Nc, nx)) < 1e-13
+
+
+def test_lpv_rk4_golden(golden):
+    from nmpc_amd.lpvrk4 import lpv_rk4
+    l = golden["lpv"]
+    xn = lpv_rk4(l["x"], l["u"], l["int_A"], l["int_B"], 0.1, l["rk4_c"])
+    assert np.abs(xn.cpu().numpy() - l["rk4_next"]).max() < 1e-14
+    xn1 = lpv_rk4(l["x"][2], l["u"][2], l["int_A"][2], l["int_B"][2], 0.1, l["rk4_c"])
+    assert xn1.shape == (2,) and np.abs(xn1.cpu().numpy() - l["rk4_next"][2]).max() < 1e-14
+
+
+def soft_qp(n, m, rng):
+    M = rng.standard_normal((n, n)); P = M @ M.T + 10.0 ** rng.uniform(-2, 0) * np.eye(n)
+    q = rng.standard_normal(n) * 3
+    G = np.hstack([rng.standard_normal((m, n)), -np.ones((m, 1))]); h = rng.uniform(-0.2, 1, m)
+    P = np.block([[P, np.zeros((n, 1))], [np.zeros((1, n)), np.array([[1000.0]])]])
+    return P, np.append(q, 0), G, h
+
+
+@pytest.mark.parametrize("n,m", [(10, 42), (3, 5), (1, 1), (15, 64), (10, 64), (39, 100), (50, 202)])
+def test_qp_vs_oracle(n, m):
+    import nmpc_amd
+    rng = np.random.default_rng(n * 100 + m)
+    nb = 24 if n > 20 else 96
+    probs = [soft_qp(n, m, rng) for _ in range(nb)]
+    st = lambda i: np.stack([p[i] for p in probs])
+    z, lam, status, it = nmpc_amd.solve_qp(st(0), st(1), st(2), st(3), return_info=True)
+    assert int(status.abs().sum()) == 0
+    z = z.cpu().numpy(); lam = lam.cpu().numpy()
+    for i in range(nb):
+        zo = osolve(*probs[i])
+        assert np.abs(zo - z[i]).max() / max(1, np.abs(zo).max()) < 1e-9
+        assert kkt_residual(*probs[i], z[i], lam[i]) < 1e-9
+
+
+def test_qp_special_cases():
+    import nmpc_amd
+    rng = np.random.default_rng(9)
+    # no constraints, inactive constraints, duplicated constraints, shared G/h across the batch
+    P = np.stack([np.eye(4) * (i + 1) for i in range(5)]); q = rng.standard_normal((5, 4))
+    z = nmpc_amd.solve_qp(P, q).cpu().numpy()
+    assert np.allclose(z, -q / np.arange(1, 6)[:, None], atol=1e-13)
+    G = np.vstack([np.eye(4), np.eye(4)]); h = np.full(8, 0.1)
+    z = nmpc_amd.solve_qp(P, q, G, h).cpu().numpy()
+    for i in range(5):
+        assert np.abs(z[i] - osolve(P[i], q[i], G, h)).max() < 1e-11
+    # equalities (flipped and unflipped rows) with inequalities
+    for t in range(20):
+        n = 6; M = rng.standard_normal((n, n)); Pm = M @ M.T + 0.1 * np.eye(n); qv = rng.standard_normal(n)
+        Gm = rng.standard_normal((9, n)); hv = rng.uniform(0.1, 1, 9); A = rng.standard_normal((2, n)); b = 0.1 * rng.standard_normal(2)
+        zt, lam, status, _ = nmpc_amd.solve_qp(Pm, qv, Gm, hv, A, b, return_info=True)
+        assert int(status) == 0
+        assert np.abs(zt.cpu().numpy() - osolve(Pm, qv, Gm, hv, A, b)).max() < 1e-10
+        assert np.abs(A @ zt.cpu().numpy() - b).max() < 1e-11
+    # infeasible and indefinite problems are reported, not silently "solved"
+    Pm = np.eye(3); qv = np.ones(3)
+    _, _, status, _ = nmpc_amd.solve_qp(Pm, qv, np.array([[1.0, 0, 0], [-1.0, 0, 0]]), np.array([-1.0, -1.0]), return_info=True)
+    assert int(status) == 2
+    _, _, status, _ = nmpc_amd.solve_qp(np.diag([1.0, -1.0, 1.0]), qv, return_info=True)
+    assert int(status) == 3
+    with pytest.raises(nmpc_amd.NmpcError):
+        nmpc_amd.solve_qp(np.diag([1.0, -1.0, 1.0]), qv)
+
+
+def test_mpc_qp_vs_oracle(enc, omodel):
+    """Assembly (G, F, L, h of NMPC_test.py:211-226) and solution of the condensed QP."""
+    import nmpc_amd
+    s = disc_setup(omodel)
+    Nc, nx, nu, ny = 10, 2, 1, 1
+    rng = np.random.default_rng(1)
+    nodes, weights = olpv.merge_nodes(*olpv.quad_nodes("simpson", 20))
+    Psi = omu.getPsi(Nc, s["R"]); Om = omu.getOmega(Nc, s["Q"])
+    D, E, M, c = omu.getDEMc_out(s["ymin"], s["ymax"], s["umin"], s["umax"], Nc, ny, nu)
+    ins, outs = [], []
+    for t in range(48):
+        x0 = rng.uniform(-2, 2, 2); xs = rng.uniform(-2, 2, (Nc, 2)); u = rng.uniform(-2.5, 2.5, (Nc, 1)); xc = rng.uniform(-2, 2, (Nc, 2))
+        A, B, C = olpv.embed(omodel, xs, u, nodes, weights, xc=xc)
+        Xs = np.tile(rng.uniform(-2, 2, 2), Nc); Us = np.tile(rng.uniform(-1, 1), Nc); ym = rng.uniform(-3, 3)
+        ins.append((A.reshape(-1, 2), B.reshape(-1, 1), C.reshape(-1, 2), x0, ym, Xs, Us))
+        outs.append(omq(*ins[-1], omodel.f0, omodel.h0, Psi, Om, D, E, M, c, Nc, nx, nu, ny, s["rho"]))
+    st = lambda i: np.stack([x[i] for x in ins])
+    for gs in ("64", "16"):
+        import os
+        os.environ["NMPC_MPC_GS"] = gs
+        r = nmpc_amd.mpc_qp(st(0), st(1), st(2), st(3), st(4), st(5), st(6), omodel.f0, omodel.h0, s["Q"], s["R"], s["rho"],
+                            s["umin"], s["umax"], s["ymin"][0], s["ymax"][0], Nc, nx, want_matrices=True)
+        g = {k: v.cpu().numpy() for k, v in r.items()}
+        assert not g["status"].any()
+        for i, (uo, eo, xpo, pc) in enumerate(outs):
+            assert rel(np.tril(g["Ge"][i]), np.tril(pc["Ge"])) < 1e-13
+            assert rel(g["Fe"][i], pc["Fe"]) < 1e-12 and rel(g["Le"][i], pc["Le"]) < 1e-13 and rel(g["h"][i], pc["h"]) < 1e-13
+            assert rel(g["u"][i], uo) < 1e-10 and abs(g["eps"][i] - eo) < 1e-10 and rel(g["xpred"][i], xpo) < 1e-10
+    os.environ.pop("NMPC_MPC_GS", None)

@@ -1,0 +1,103 @@
+"""GPU parity tests of the LPV embedding kernel through the C ABI (nmpc_lpv_embed) against the
+fp64 oracle and the golden vectors of the reference's lpv_int.py.
+Bar: A_k, B_k, C_k within 1e-5 relative (fp32 kernel)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lpv as olpv
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def relerr(got, ref):
+    """worst over points of ||got - ref||_max / ||ref||_max per matrix"""
+    got = np.asarray(got, np.float64).reshape(ref.shape)
+    num = np.abs(got - ref).reshape(ref.shape[0], -1).max(1)
+    den = np.abs(ref).reshape(ref.shape[0], -1).max(1)
+    return float((num / den).max())
+
+
+def f32(a):
+    return np.asarray(a, np.float32).astype(np.float64)
+
+
+@pytest.mark.parametrize("P", [1, 15, 16, 17, 33, 1000])
+@pytest.mark.parametrize("rule,stages,dlam", [("simpson", 20, None), ("trap", 20, None), ("simpson", 7, 0.1)])
+def test_embed_vs_oracle(enc, omodel, P, rule, stages, dlam):
+    import nmpc_amd
+    rng = np.random.default_rng(P * 31 + stages)
+    x = f32(rng.uniform(-3, 3, (P, 2))); u = f32(rng.uniform(-3, 3, (P, 1))); xc = f32(rng.uniform(-3, 3, (P, 2)))
+    lam, w = nmpc_amd.quad_nodes(rule, stages, dlam)
+    A, B, C = nmpc_amd.embed(enc, torch.tensor(x), torch.tensor(u), torch.tensor(xc), lam, w)
+    Ao, Bo, Co = olpv.embed(omodel, x, u, *olpv.merge_nodes(*olpv.quad_nodes(rule, stages, dlam)), xc=xc)
+    assert relerr(A.cpu(), Ao) < TOL and relerr(B.cpu(), Bo) < TOL and relerr(C.cpu(), Co) < TOL
+
+
+def test_reference_entry_points_on_golden(enc, golden):
+    """lpv_int / lpv_int_C / lambda_simpson / lambda_trap / par_lpv_int with the reference's
+    signatures reproduce what the reference's lpv_int.py returned for the same inputs."""
+    import nmpc_amd
+    l = golden["lpv"]
+    x, u = torch.tensor(l["x"]), torch.tensor(l["u"])
+    Jfx, Jfu, Jhx = nmpc_amd.jacobians(enc)
+    A, B = nmpc_amd.lpv_int(x, 2, u, 1, Jfx, Jfu, 0.05, 20)
+    assert relerr(A.cpu(), l["int_A"]) < TOL and relerr(B.cpu(), l["int_B"]) < TOL
+    A, B, C = nmpc_amd.lpv_int_C(x, 2, u, 1, 1, Jfx, Jfu, Jhx, 0.05, 20)
+    assert relerr(A.cpu(), l["intC_A"]) < TOL and relerr(C.cpu(), l["intC_C"]) < TOL
+    A, B, C = nmpc_amd.lambda_simpson(x, u, 2, 1, 1, Jfx, Jfu, Jhx, 20)
+    assert relerr(A.cpu(), l["simp_A"]) < TOL and relerr(B.cpu(), l["simp_B"]) < TOL and relerr(C.cpu(), l["simp_C"]) < TOL
+    A, B, C = nmpc_amd.lambda_trap(x, u, 2, 1, 1, Jfx, Jfu, Jhx, 20)
+    assert relerr(A.cpu(), l["trap_A"]) < TOL and relerr(B.cpu(), l["trap_B"]) < TOL and relerr(C.cpu(), l["trap_C"]) < TOL
+    A, B = nmpc_amd.lpv_int(x, 2, u, 1, Jfx, Jfu, 0.1, 7)
+    assert relerr(A.cpu(), l["odd_A"]) < TOL and relerr(B.cpu(), l["odd_B"]) < TOL
+    L = np.concatenate([np.arange(20) * 0.05, np.arange(20) * 0.05 + 0.025, np.arange(20) * 0.05 + 0.05])
+    A, B = nmpc_amd.par_lpv_int(x, 2, u, 1, Jfx, Jfu, 0.05, 20, L)
+    assert relerr(A.cpu(), l["int_A"]) < TOL and relerr(B.cpu(), l["int_B"]) < TOL
+    # single un-batched point, as the reference calls it
+    A, B = nmpc_amd.lpv_int(x[3], 2, u[3], 1, Jfx, Jfu, 0.05, 20)
+    assert A.shape == (2, 2) and B.shape == (2, 1)
+    assert np.abs(A.cpu().numpy() - l["int_A"][3]).max() < 1e-5
+
+
+def test_edge_cases(enc, omodel):
+    import nmpc_amd
+    # zero scheduling point: every node sees J(0); Observer.ipynb cell 12 (stages = 100 -> 201 nodes)
+    lam, w = nmpc_amd.quad_nodes("simpson", 100)
+    assert len(lam) == 201
+    _, _, C = nmpc_amd.embed(enc, None, None, torch.zeros(1, 2), lam, w)
+    assert np.abs(C.cpu().numpy() - [[-5.23925331, -2.59772804]]).max() < 1e-5
+    # saturated tanh units, one-node rule, C-only and AB-only calls
+    x = np.array([[50.0, -50.0], [1e-4, -1e-4], [0.0, 7.5]]); u = np.array([[30.0], [0.0], [-9.0]])
+    for lam, w in ((np.array([1.0], np.float32), np.array([1.0], np.float32)), nmpc_amd.quad_nodes("simpson", 20)):
+        A, B, C0 = nmpc_amd.embed(enc, torch.tensor(x), torch.tensor(u), None, lam, w)
+        assert C0 is None
+        Ao, Bo, Co = olpv.embed(omodel, f32(x), f32(u), lam.astype(float), w.astype(float))
+        assert np.isfinite(A.cpu().numpy()).all()
+        assert relerr(A.cpu(), Ao) < TOL and relerr(B.cpu(), Bo) < TOL
+        _, _, C = nmpc_amd.embed(enc, None, None, torch.tensor(x), lam, w)
+        assert relerr(C.cpu(), Co) < TOL
+    with pytest.raises(nmpc_amd.NmpcError):
+        nmpc_amd.embed(enc, torch.zeros(2, 2), torch.zeros(2, 1), None, np.zeros(300, np.float32), np.zeros(300, np.float32))
+
+
+def test_full_size_properties(enc, omodel):
+    """B*Nc = 40960 points (the benchmark's launch): bitwise reproducible, independent of how the
+    points are ordered into tiles, and correct on a sample."""
+    import nmpc_amd
+    P = 40960
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(P, 2, generator=g) * 4 - 2).cuda(); u = (torch.rand(P, 1, generator=g) * 6 - 3).cuda()
+    xc = (torch.rand(P, 2, generator=g) * 4 - 2).cuda()
+    lam, w = nmpc_amd.quad_nodes("simpson", 20)
+    A1, B1, C1 = nmpc_amd.embed(enc, x, u, xc, lam, w)
+    A2, B2, C2 = nmpc_amd.embed(enc, x, u, xc, lam, w)
+    assert torch.equal(A1, A2) and torch.equal(B1, B2) and torch.equal(C1, C2)
+    perm = torch.randperm(P, generator=g).cuda()
+    A3, B3, C3 = nmpc_amd.embed(enc, x[perm], u[perm], xc[perm], lam, w)
+    assert torch.equal(A3, A1[perm]) and torch.equal(B3, B1[perm]) and torch.equal(C3, C1[perm])
+    idx = torch.arange(0, P, 97)
+    Ao, Bo, Co = olpv.embed(omodel, x[idx].cpu().double().numpy(), u[idx].cpu().double().numpy(),
+                            *olpv.merge_nodes(*olpv.quad_nodes("simpson", 20)), xc=xc[idx].cpu().double().numpy())
+    assert relerr(A1[idx].cpu(), Ao) < TOL and relerr(B1[idx].cpu(), Bo) < TOL and relerr(C1[idx].cpu(), Co) < TOL

@@ -1,0 +1,186 @@
+"""CPU tests: the fp64 oracle against the golden vectors produced by the reference's own NumPy
+functions (tools/make_golden.py) and against the numeric known-answers in its notebooks."""
+import numpy as np
+import pytest
+
+from oracle import lpv, mpcutil
+from oracle.qp import solve_qp, kkt_residual, QPError
+from oracle.plant import disc_step, random_level_reference
+from conftest import disc_setup
+
+
+def rel(a, b):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(1.0, np.max(np.abs(b)))
+
+
+def test_derived_constants(omodel):
+    # values recoverable from the raw weights alone
+    assert np.allclose(omodel.f0, [-0.03403033, 0.12136981], atol=1e-8)
+    assert np.allclose(omodel.h0, [-0.24081322], atol=1e-8)
+    J0 = omodel.Jf(np.zeros(2), np.zeros(1))
+    assert np.allclose(J0, [[0.12734827, -0.52502991, -0.11341954], [1.29652171, 0.67557925, 0.10133324]], atol=1e-8)
+
+
+def test_known_answer_observer_notebook(omodel):
+    # Observer.ipynb cell 12: get_C(0, 0) with lpv_int_C, stages = 100
+    n, w = lpv.quad_nodes("simpson", 100, 1.0 / 100)
+    _, _, C = lpv.embed(omodel, np.zeros(2), np.zeros(1), n, w)
+    assert np.allclose(C, [[-5.23925331, -2.59772804]], atol=5e-9)
+
+
+def test_known_answer_getF0_notebook():
+    # NumpyLinearNMPC.ipynb cells 12-13: list_A (Nc = 4) and the matrix sum_j P_j before "@ f0"
+    list_A = np.array([[0.21917246, 0.26985018], [-1.03306645, 0.51417798], [0.36560131, 0.34343052],
+                       [-1.3875607, 0.45466903], [0.27050238, 0.36154198], [-1.50674346, 0.53530089],
+                       [0.35240265, 0.39804248], [-1.51583822, 0.55563059]])
+    F0mat = np.array([[1.0, 0.0], [0.0, 1.0], [1.36560131, 0.34343052], [-1.3875607, 1.45466903],
+                      [0.96283589, 0.60071124], [-2.68119055, 1.18059208], [0.30598065, 0.58228338],
+                      [-2.78944365, 0.63831059]])
+    got = np.hstack([mpcutil.getF0(list_A, e, 4, 2) for e in np.eye(2)])
+    assert np.allclose(got, F0mat, atol=2e-8)
+
+
+def test_condense_golden(golden):
+    g = golden["condense"]
+    for ci, (Nc, nx, nu, ny) in enumerate(g["cases"]):
+        k = "c%d_" % ci
+        lA, lB, lC, f0 = g[k + "list_A"], g[k + "list_B"], g[k + "list_C"], g[k + "f0"]
+        assert rel(mpcutil.getPhi(lA, Nc, nx, nu), g[k + "Phi"]) < 1e-13
+        assert rel(mpcutil.getGamma(lA, lB, Nc, nx, nu), g[k + "Gamma"]) < 1e-13
+        assert rel(mpcutil.getF0(lA, f0, Nc, nx), g[k + "F0"]) < 1e-13
+        assert np.array_equal(mpcutil.getZ(lC, Nc, ny, nx), g[k + "Z"])
+        assert np.array_equal(mpcutil.getPsi(Nc, g[k + "R"]), g[k + "Psi"])
+        assert np.array_equal(mpcutil.getOmega(Nc, g[k + "Q"]), g[k + "Omega"])
+        b = g[k + "bounds"]
+        lo, hi, ylo, yhi = b[:nx], b[nx:2 * nx], b[2 * nx:2 * nx + ny], b[2 * nx + ny:2 * nx + 2 * ny]
+        for nm, v in zip("DEMc", mpcutil.getDEMc(lo, hi, b[-2], b[-1], Nc, nx, nu)):
+            assert np.array_equal(v, g[k + "st_" + nm]), nm
+        for nm, v in zip("DEMc", mpcutil.getDEMc_out(ylo, yhi, b[-2], b[-1], Nc, ny, nu)):
+            assert np.array_equal(v, g[k + "out_" + nm]), nm
+
+
+def test_jacobian_golden(golden, omodel):
+    j = golden["jac"]
+    J = omodel.Jf(j["x"], j["u"])
+    assert np.abs(J[..., :2] - j["Jfx"]).max() < 1e-12
+    assert np.abs(J[..., 2:] - j["Jfu"]).max() < 1e-12
+    assert np.abs(omodel.Jhx(j["x"]) - j["Jhx"]).max() < 1e-11
+
+
+def test_quadrature_golden(golden, omodel):
+    l = golden["lpv"]
+    x, u = l["x"], l["u"]
+    for key, rule, stages, dlam in (("int", "simpson", 20, 0.05), ("simp", "simpson", 20, None),
+                                    ("trap", "trap", 20, None), ("odd", "simpson", 7, 0.1)):
+        n, w = lpv.quad_nodes(rule, stages, dlam)
+        A, B, C = lpv.embed(omodel, x, u, n, w)
+        assert np.abs(A - l[key + "_A"]).max() < 1e-13
+        assert np.abs(B - l[key + "_B"]).max() < 1e-13
+        if key + "_C" in l:
+            assert np.abs(C - l[key + "_C"]).max() < 1e-12
+        # merging bit-identical nodes changes only the summation order
+        A2, B2, _ = lpv.embed(omodel, x, u, *lpv.merge_nodes(n, w))
+        assert np.abs(A2 - A).max() < 1e-13 and np.abs(B2 - B).max() < 1e-13
+    assert len(lpv.merge_nodes(*lpv.quad_nodes("simpson", 20))[0]) == 41
+    nx = lpv.lpv_rk4(x, u, l["int_A"], l["int_B"], 0.1, l["rk4_c"])
+    assert np.abs(nx - l["rk4_next"]).max() < 1e-14
+
+
+def test_reference_named_entry_points(golden, omodel):
+    l = golden["lpv"]
+    x, u = l["x"][3], l["u"][3]
+    A, B = lpv.lpv_int(x, 2, u, 1, omodel.Jfx, omodel.Jfu, 0.05, 20)
+    assert np.allclose(A, l["int_A"][3], atol=1e-13) and np.allclose(B, l["int_B"][3], atol=1e-13)
+    A, B, C = lpv.lambda_trap(x, u, 2, 1, 1, omodel.Jfx, omodel.Jfu, omodel.Jhx, 20)
+    assert np.allclose(C, l["trap_C"][3], atol=1e-12)
+    L = np.concatenate([np.arange(20) * 0.05, np.arange(20) * 0.05 + 0.025, np.arange(20) * 0.05 + 0.05])
+    A, B = lpv.par_lpv_int(x, 2, u, 1, omodel.Jfx, omodel.Jfu, 0.05, 20, L)
+    assert np.allclose(A, l["int_A"][3], atol=1e-12)
+
+
+def test_qp_kkt_and_scipy():
+    from scipy.optimize import minimize
+    rng = np.random.default_rng(0)
+    for trial in range(60):
+        n = int(rng.integers(2, 13)); m = int(rng.integers(1, 45))
+        M = rng.standard_normal((n, n)); P = M @ M.T + 10.0 ** rng.uniform(-3, 0) * np.eye(n)
+        q = rng.standard_normal(n) * 3
+        G = np.hstack([rng.standard_normal((m, n)), -np.ones((m, 1))]); h = rng.uniform(-0.2, 1, m)
+        P = np.block([[P, np.zeros((n, 1))], [np.zeros((1, n)), np.array([[1000.0]])]]); q = np.append(q, 0)
+        x, lam, _ = solve_qp(P, q, G, h, return_dual=True)
+        assert kkt_residual(P, q, G, h, x, lam) < 1e-9
+        if trial < 6:
+            res = minimize(lambda z: 0.5 * z @ P @ z + q @ z, np.zeros(n + 1), jac=lambda z: P @ z + q,
+                           constraints=[{"type": "ineq", "fun": lambda z: h - G @ z, "jac": lambda z: -G}],
+                           method="SLSQP", options={"ftol": 1e-14, "maxiter": 500})
+            assert np.abs(res.x - x).max() < 1e-5
+    # unconstrained / inactive / infeasible
+    P = np.eye(3); q = np.array([1.0, -2.0, 0.5])
+    assert np.allclose(solve_qp(P, q), -q)
+    assert np.allclose(solve_qp(P, q, np.eye(3), 10 * np.ones(3)), -q)
+    with pytest.raises(QPError):
+        solve_qp(P, q, np.array([[1.0, 0, 0], [-1.0, 0, 0]]), np.array([-1.0, -1.0]))
+
+
+def test_qp_equalities_with_singular_hessian():
+    rng = np.random.default_rng(3)
+    for _ in range(10):
+        c = rng.standard_normal((1, 2))
+        P = np.diag([0, 0, 1.0, 1000.0]); P[:2, :2] = c.T @ c
+        A = np.hstack([rng.standard_normal((3, 3)), np.zeros((3, 1))]); b = rng.standard_normal(3)
+        q = np.append(rng.standard_normal(2), [0, 0])
+        G = np.zeros((4, 4)); G[0, 2] = -1; G[1, 2] = 1; G[2, :2] = -c; G[3, :2] = c; G[:, 3] = -1
+        h = np.array([0.5, 0.5, 0.3, 0.3])
+        x, lam, _ = solve_qp(P, q, G, h, A, b, return_dual=True)
+        assert kkt_residual(P, q, G, h, x, lam, A, b) < 1e-9
+        # the three equalities pin (xs, us); the slack is the worst violation
+        z = np.linalg.solve(A[:, :3], b)
+        assert np.allclose(x[:3], z, atol=1e-9)
+        assert np.isclose(x[3], max(0.0, np.max(G[:, :3] @ z - h)), atol=1e-9)
+
+
+def test_plant_and_reference_generator():
+    x = disc_step(np.array([0.0, 0.0]), 1.0, 0.1)
+    assert x.shape == (2,) and x[0] > 0 and x[1] > 0
+    xb = disc_step(np.zeros((5, 2)), np.ones(5), 0.1)
+    assert np.allclose(xb, x)
+    r = random_level_reference(200, [10, 15], [-1, 1], np.random.default_rng(1))
+    assert r.size == 200 and np.all(np.abs(r) <= 1.0) and np.allclose(r * 10, np.round(r * 10))
+    runs = np.diff(np.flatnonzero(np.concatenate([[True], np.diff(r) != 0, [True]])))
+    assert runs[:-1].min() >= 10          # equal neighbouring levels may merge segments; none is shorter
+
+
+def test_closed_loop_oracle_tracks(omodel):
+    from oracle.nmpc import output_nmpc_linear
+    ref = np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "ref_randomLevelTime10_15Range-1_1Nsim200.npy"))
+    yref = np.clip(ref[1], -1.2, 1.2)
+    Nsim = 40
+    r = output_nmpc_linear(omodel, -4, 4, [-1.2], [1.2], np.zeros(2), np.diag([1000.0, 10.0]), 1.0, 0.1, 20, yref,
+                           Nc=10, Nsim=Nsim, max_iterations=4)
+    assert set(np.unique(r["lpv_counter"])) <= {1, 2, 3, 4}
+    assert abs(r["y_log"][9] - (-1.0)) < 0.05 and abs(r["y_log"][24]) < 0.05     # settles on the first two levels
+    assert r["u_log"].min() >= -4 - 1e-6 and r["u_log"].max() <= 4 + 1e-6
+    # merged (41 nodes) and as-written (60 nodes) quadrature give the same loop to rounding
+    r2 = output_nmpc_linear(omodel, -4, 4, [-1.2], [1.2], np.zeros(2), np.diag([1000.0, 10.0]), 1.0, 0.1, 20, yref,
+                            Nc=10, Nsim=10, max_iterations=4, merge=False, targets=(r["Xs"], r["Us"]))
+    assert np.abs(r2["u_log"] - r["u_log"][:10]).max() < 1e-9
+
+
+def test_mpc_qp_matches_generic_form(omodel):
+    """The condensed QP pieces against a direct evaluation of NMPC_test.py:211-217."""
+    from oracle.nmpc import mpc_qp
+    s = disc_setup(omodel)
+    rng = np.random.default_rng(5)
+    Nc, nx, nu, ny = 10, 2, 1, 1
+    lA = rng.uniform(-1, 1, (Nc * nx, nx)); lB = rng.uniform(-1, 1, (Nc * nx, nu)); lC = rng.uniform(-2, 2, (Nc, nx))
+    x0 = rng.uniform(-1, 1, nx); Xs = rng.uniform(-1, 1, Nc * nx); Us = rng.uniform(-1, 1, Nc); ym = 0.3
+    Psi = mpcutil.getPsi(Nc, s["R"]); Om = mpcutil.getOmega(Nc, s["Q"])
+    D, E, M, c = mpcutil.getDEMc_out(s["ymin"], s["ymax"], s["umin"], s["umax"], Nc, ny, nu)
+    u, eps, xp, pc = mpc_qp(lA, lB, lC, x0, ym, Xs, Us, omodel.f0, omodel.h0, Psi, Om, D, E, M, c, Nc, nx, nu, ny, 1000.0)
+    Phi, Gam, F0, Z = pc["Phi"], pc["Gamma"], pc["F0"], pc["Z"]
+    assert np.allclose(pc["G"], 2 * (Psi + Gam.T @ Om @ Gam))
+    assert np.allclose(pc["L"], M @ Z @ Gam + E)
+    H0 = np.tile(omodel.h0, Nc)
+    assert np.allclose(pc["h"], c[:, 0] - D @ [ym] - M @ Z @ (Phi @ x0 + F0) - M @ H0)
+    assert np.allclose(xp, Phi @ x0 + Gam @ u + F0)
+    assert np.all(pc["Le"] @ np.append(u, eps) <= pc["h"] + 1e-9)
