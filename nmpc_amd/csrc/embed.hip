@@ -42,8 +42,10 @@ __device__ __forceinline__ void embed_tile(const float* __restrict__ pack, float
                                            float* __restrict__ oa, float* __restrict__ ob, int tile, int npts,
                                            const int* __restrict__ act, int group, const NodeTable& nt) {
     constexpr int NIN = NA + NB;
+    // the cross-wave reduction buffer aliases the (by then dead) forward fragments
     constexpr int L_WR = 4096, L_REC1 = 4096 + 4096 * NOUT, L_REC2 = L_REC1 + 256, L_LIN = L_REC2 + 256,
-                  L_RED = L_LIN + 16;
+                  L_RED = 0;
+    static_assert(4 * EMBED_TILE * NOUT * NIN <= 4096, "reduction buffer must fit in the WF region");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, hq = lane >> 4;
@@ -162,6 +164,7 @@ __device__ __forceinline__ void embed_tile(const float* __restrict__ pack, float
             for (int j = 0; j < NIN; ++j) pj[c][j] = fmaf(q[c][s], w0[j], pj[c][j]);
     }
     float* red = lds + L_RED;
+    __syncthreads();          // every wave has finished reading WF
 #pragma unroll
     for (int c = 0; c < NOUT; ++c)
 #pragma unroll
@@ -191,7 +194,7 @@ __device__ __forceinline__ void embed_tile(const float* __restrict__ pack, float
 }
 
 template <int NX, int NU, int NY>
-__global__ __launch_bounds__(EMBED_THREADS, 2) void embed_kernel(EmbedArgs a, NodeTable nt) {
+__global__ __launch_bounds__(EMBED_THREADS, 3) void embed_kernel(EmbedArgs a, NodeTable nt) {
     extern __shared__ __align__(16) float lds[];
     int npts = a.npts;
     if (a.count_dev) npts = min(npts, *a.count_dev * a.group);
@@ -218,7 +221,7 @@ int embed_launch(const ModelDev& m, EmbedArgs a, const NodeTable& nt, hipStream_
     if (a.group < 1) a.group = 1;
     const int grid = a.n_ftiles + (do_h ? tiles : 0);
     const int nout_max = m.nx > m.ny ? m.nx : m.ny;
-    const size_t lds_bytes = sizeof(float) * (4096 + 4096 * nout_max + PK_TAIL + 4 * EMBED_TILE * 16);
+    const size_t lds_bytes = sizeof(float) * (4096 + 4096 * nout_max + PK_TAIL);
 #define NMPC_EMBED_CASE(NX_, NU_, NY_)                                                            \
     if (m.nx == NX_ && m.nu == NU_ && m.ny == NY_) {                                              \
         static bool attr_set = false;                                                             \
