@@ -44,6 +44,23 @@ def random_level_reference(n, nt_range, level_range, rng):
             return out[:n]
 
 
+def pmc_traffic_bytes():
+    """HBM bytes per embedding launch from the committed rocprofv3 --pmc passes of this same
+    command (profiles/): FETCH_SIZE and WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts
+    half of the bytes of wide coalesced reads, hence the factor 2.  None if no profile is there."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_embed_loop.txt")))
+    if not files:
+        return None, None
+    txt = open(files[-1]).read()
+    f = re.search(r"FETCH_SIZE\s+n=\d+ mean=([0-9.e+]+)", txt)
+    w = re.search(r"WRITE_SIZE\s+n=\d+ mean=([0-9.e+]+)", txt)
+    if not (f and w):
+        return None, None
+    return (2.0 * float(f.group(1)) + float(w.group(1))) * 1024.0, os.path.relpath(files[-1], ROOT)
+
+
 def cpu_baseline(n_ctrl, n_steps, refs):
     """The fp64 NumPy oracle (a restatement of the reference's CPU path) timed on this host, one
     thread, on the first n_ctrl controllers x n_steps steps of the same workload."""
@@ -151,6 +168,7 @@ def main():
         achieved = embed_flops / (ms_embed * 1e-3) / 1e12
         y = gathered["y_log"][:, W + 1:W + K + 1]
         track = float((y[:B] - torch.as_tensor(refs[:, W:W + K], device=dev)).abs().median().item())
+        traffic, traffic_src = pmc_traffic_bytes()
         res = {
             "metric": "closed-loop NMPC controller-steps/sec (B=4096, N=10)",
             "value": value, "unit": "controller-steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -168,7 +186,8 @@ def main():
             "target_selector_s": t_targets, "final_gather_s": t_gather,
             "median_abs_tracking_error": track,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "bytes per launch (HBM, PMC)", "traffic_source": traffic_src,
                          "kernel": "embed_kernel", "launches": n_launch,
                          "avg_launch_ms": ms_embed / max(n_launch, 1),
                          "flops_per_launch": embed_flops / max(n_launch, 1)},

@@ -664,7 +664,7 @@ extern "C" int nmpc_ctrl_run(nmpc_ctrl* c, int k0, int nsteps, const double* Xs,
             if (it > 0) { a.count_dev = d.nact + it; a.act = d.act + (size_t)it * d.B; }
             ProfRec pr;
             bool on = prof_begin(c, 0, s, pr);
-            if (embed_launch(c->m, a, c->nt, s)) return 1;
+            if (embed_launch(c->m, a, c->nt, s, true)) return 1;
             prof_end(c, on, s, pr);
             on = prof_begin(c, 1, s, pr);
             if (dispatch_mpc_solve(d, rp, it, k, c->g, s)) return 1;

@@ -30,6 +30,6 @@ struct EmbedArgs {
     int n_ftiles;
 };
 
-int embed_launch(const ModelDev& m, EmbedArgs a, const NodeTable& nt, hipStream_t stream);
+int embed_launch(const ModelDev& m, EmbedArgs a, const NodeTable& nt, hipStream_t stream, bool loop = false);
 
 }  // namespace nmpc

@@ -193,7 +193,9 @@ __device__ __forceinline__ void embed_tile(const float* __restrict__ pack, float
     }
 }
 
-template <int NX, int NU, int NY>
+// LOOP tags the launches made from the closed-loop step so that a profiler lists them apart from
+// the set-up launches (target selector, stand-alone calls); the code is identical.
+template <int NX, int NU, int NY, bool LOOP>
 __global__ __launch_bounds__(EMBED_THREADS, 3) void embed_kernel(EmbedArgs a, NodeTable nt) {
     extern __shared__ __align__(16) float lds[];
     int npts = a.npts;
@@ -209,7 +211,20 @@ __global__ __launch_bounds__(EMBED_THREADS, 3) void embed_kernel(EmbedArgs a, No
     }
 }
 
-int embed_launch(const ModelDev& m, EmbedArgs a, const NodeTable& nt, hipStream_t stream) {
+template <int NX, int NU, int NY, bool LOOP>
+static int embed_launch_t(const EmbedArgs& a, const NodeTable& nt, int grid, size_t lds_bytes, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        NMPC_HIP_CHECK(hipFuncSetAttribute((const void*)embed_kernel<NX, NU, NY, LOOP>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((embed_kernel<NX, NU, NY, LOOP>), dim3(grid), dim3(EMBED_THREADS), lds_bytes, stream, a, nt);
+    NMPC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int embed_launch(const ModelDev& m, EmbedArgs a, const NodeTable& nt, hipStream_t stream, bool loop) {
     NMPC_REQUIRE(nt.n >= 1 && nt.n <= NMPC_MAX_NODES, "embed: node count %d out of range", nt.n);
     NMPC_REQUIRE(a.npts >= 0, "embed: negative point count");
     if (a.npts == 0) return 0;
@@ -223,17 +238,9 @@ int embed_launch(const ModelDev& m, EmbedArgs a, const NodeTable& nt, hipStream_
     const int nout_max = m.nx > m.ny ? m.nx : m.ny;
     const size_t lds_bytes = sizeof(float) * (4096 + 4096 * nout_max + PK_TAIL);
 #define NMPC_EMBED_CASE(NX_, NU_, NY_)                                                            \
-    if (m.nx == NX_ && m.nu == NU_ && m.ny == NY_) {                                              \
-        static bool attr_set = false;                                                             \
-        if (!attr_set) {                                                                          \
-            NMPC_HIP_CHECK(hipFuncSetAttribute((const void*)embed_kernel<NX_, NU_, NY_>,          \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-            attr_set = true;                                                                      \
-        }                                                                                         \
-        hipLaunchKernelGGL((embed_kernel<NX_, NU_, NY_>), dim3(grid), dim3(EMBED_THREADS), lds_bytes, stream, a, nt); \
-        NMPC_HIP_CHECK(hipGetLastError());                                                        \
-        return 0;                                                                                 \
-    }
+    if (m.nx == NX_ && m.nu == NU_ && m.ny == NY_)                                                \
+        return loop ? embed_launch_t<NX_, NU_, NY_, true>(a, nt, grid, lds_bytes, stream)         \
+                    : embed_launch_t<NX_, NU_, NY_, false>(a, nt, grid, lds_bytes, stream);
     NMPC_EMBED_CASE(2, 1, 1)
     NMPC_EMBED_CASE(3, 1, 1)
     NMPC_EMBED_CASE(2, 2, 1)
