@@ -41,8 +41,10 @@ constexpr int PK_TAIL = PACK_FLOATS - PK_REC1;   // REC1 + REC2 + LIN, contiguou
 // Device-resident packed networks.
 struct ModelDev {
     int nx, nu, ny, hidden, n_enc_in;
-    float* fpack;   // f-net, MFMA layout
-    float* hpack;   // h-net, MFMA layout
+    float* fpack;   // f-net, fp32 MFMA layout
+    float* hpack;   // h-net, fp32 MFMA layout
+    float* fpack_h2;   // f-net, split-fp16 MFMA layout (same offsets, fragment regions hold halves)
+    float* hpack_h2;   // h-net, split-fp16 MFMA layout
     float* enc;     // observer net, plain row-major params concatenated (may be null):
                     // lin_w[out,in] lin_b w0[H,in] b0 w2[H,H] b2 w4[out,H] b4 w2^T[H,H]
     float* hplain;  // h-net in the same plain layout (for the output estimate)

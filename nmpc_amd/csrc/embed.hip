@@ -21,6 +21,9 @@
 #include "common.h"
 #include "embed.h"
 
+#include <cstdlib>
+#include <string>
+
 namespace nmpc {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -193,9 +196,209 @@ __device__ __forceinline__ void embed_tile(const float* __restrict__ pack, float
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Split-fp16 variant.  On gfx950 the fp32-input MFMA issues at the fp32 VECTOR rate and does not
+// overlap with VALU work (PMC: matrix-busy + VALU-busy cycles = kernel cycles, zero co-execution),
+// so the fp32 kernel above runs at (MFMA + VALU) time.  Here every fp32 operand x is written as
+//     x = xh + 2^-11 xl',   xh = x with its significand cut to 11 bits (exact in fp16),
+//                           xl' = fp16((x - xh) 2^11)                      (22 bits in total)
+// and a product W x is evaluated as  Wh xh + 2^-11 (Wh xl' + Wl' xh)  with three
+// v_mfma_f32_16x16x32_f16 (fp16 products are exact in the fp32 accumulator; the dropped Wl xl term
+// is 2^-22 relative).  These run on the matrix pipe at 16x the fp32 rate and concurrently with the
+// VALU, which leaves the kernel bound by the activation (v_exp/v_rcp) work.  The low parts carry a
+// 2^11 scale so that they stay in fp16's normal range; they accumulate in their own register set.
+// Unit numbering, accumulator->operand reuse and the hoisted W0 contraction are as in embed_tile:
+// element j of k-step ks of a B fragment is unit s = 8 ks + j = 4 T + r of the accumulator tiles.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& H, unsigned& L) {
+    const float ah = __uint_as_float(__float_as_uint(a) & 0xFFFFE000u);
+    const float bh = __uint_as_float(__float_as_uint(b) & 0xFFFFE000u);
+    const float al = (a - ah) * 2048.0f, bl = (b - bh) * 2048.0f;
+    H = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ah, bh));
+    L = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(al, bl));
+}
+
+// 16 fp32 values (unit order) -> B fragments of the two k-steps, high and low planes
+__device__ __forceinline__ void split16(const float* v, f16x8* BH, f16x8* BL) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        u32x4 h, l;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            unsigned hh, ll;
+            split_pair(v[8 * ks + 2 * m], v[8 * ks + 2 * m + 1], hh, ll);
+            h[m] = hh; l[m] = ll;
+        }
+        BH[ks] = __builtin_bit_cast(f16x8, h);
+        BL[ks] = __builtin_bit_cast(f16x8, l);
+    }
+}
+
+template <int NA, int NB, int NOUT>
+__device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, float* __restrict__ lds,
+                                              const float* __restrict__ pa, const float* __restrict__ pb,
+                                              float* __restrict__ oa, float* __restrict__ ob, int tile, int npts,
+                                              const int* __restrict__ act, int group, const NodeTable& nt) {
+    constexpr int NIN = NA + NB;
+    constexpr int L_WR = 4096, L_REC1 = 4096 + 4096 * NOUT, L_REC2 = L_REC1 + 256, L_LIN = L_REC2 + 256,
+                  L_RED = 0;
+    static_assert(4 * EMBED_TILE * NOUT * NIN <= 4096, "reduction buffer must fit in the WF region");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, hq = lane >> 4;
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(pack);
+        f32x4* dst = reinterpret_cast<f32x4*>(lds);
+        for (int i = tid; i < (4096 + 4096 * NOUT) / 4; i += EMBED_THREADS) dst[i] = src[i];
+        const f32x4* src2 = reinterpret_cast<const f32x4*>(pack + PK_REC1);
+        f32x4* dst2 = reinterpret_cast<f32x4*>(lds + L_REC1);
+        for (int i = tid; i < PK_TAIL / 4; i += EMBED_THREADS) dst2[i] = src2[i];
+    }
+    __syncthreads();
+    // fragment planes: [plane][T][ks][lane] of 8 halves (16 B)
+    const f16x8* WF = reinterpret_cast<const f16x8*>(lds);
+    const f16x8* WR = reinterpret_cast<const f16x8*>(lds + L_WR);
+    const f32x4* REC1 = reinterpret_cast<const f32x4*>(lds + L_REC1);
+    const f32x4* REC2 = reinterpret_cast<const f32x4*>(lds + L_REC2);
+
+    const int p = tile * EMBED_TILE + n;
+    const bool valid = p < npts;
+    const int pc = valid ? p : npts - 1;
+    const int row = act ? act[pc / group] * group + pc % group : pc;
+    float z[NIN];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) z[j] = pa[(size_t)row * NA + j];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) z[NA + j] = pb[(size_t)row * NB + j];
+
+    constexpr float C2 = 2.8853900817779268f;
+    constexpr float LO = 1.0f / 2048.0f;
+    float g[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const f32x4 w0 = REC2[kbase(s) + 4 * hq];
+        float a = w0[0] * z[0];
+#pragma unroll
+        for (int j = 1; j < NIN; ++j) a = fmaf(w0[j], z[j], a);
+        g[s] = C2 * a;
+    }
+    float q[NOUT][16];
+#pragma unroll
+    for (int c = 0; c < NOUT; ++c)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) q[c][s] = 0.0f;
+
+    const int nn = nt.n;
+    const int n0 = (nn * wave) >> 2, n1 = (nn * (wave + 1)) >> 2;
+    for (int node = n0; node < n1; ++node) {
+        const float lam = nt.lam[node];
+        const float w4 = 4.0f * nt.w[node];
+        int lo = lane, ho = 4 * hq;
+        asm volatile("" : "+v"(lo), "+v"(ho));
+        float t1[16], wd1[16];
+        f32x4 acch[4], accl[4];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const f32x4 r1 = REC1[kbase(s) + ho];
+            float er, r;
+            tanh_parts(fmaf(lam, g[s], r1[0]), er, r);
+            t1[s] = fmaf(-2.0f, r, 1.0f);
+            wd1[s] = (w4 * er) * r;
+            acch[s >> 2][s & 3] = r1[1];
+            accl[s >> 2][s & 3] = 0.0f;
+        }
+        f16x8 BH[2], BL[2];
+        split16(t1, BH, BL);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int T = 0; T < 4; ++T) {
+                const f16x8 ah = WF[((0 * 4 + T) * 2 + ks) * 64 + lo];
+                const f16x8 al = WF[((1 * 4 + T) * 2 + ks) * 64 + lo];
+                acch[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, BH[ks], acch[T], 0, 0, 0);
+                accl[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, BL[ks], accl[T], 0, 0, 0);
+                accl[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, BH[ks], accl[T], 0, 0, 0);
+            }
+        }
+        float d2q[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            float er, r;
+            tanh_parts(fmaf(accl[s >> 2][s & 3], LO, acch[s >> 2][s & 3]), er, r);
+            d2q[s] = er * r;
+        }
+        split16(d2q, BH, BL);
+#pragma unroll
+        for (int c = 0; c < NOUT; ++c) {
+            f32x4 rh[4], rl[4];
+#pragma unroll
+            for (int T = 0; T < 4; ++T) { rh[T] = f32x4{0.f, 0.f, 0.f, 0.f}; rl[T] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int T = 0; T < 4; ++T) {
+                    const f16x8 ah = WR[c * 1024 + ((0 * 4 + T) * 2 + ks) * 64 + lo];
+                    const f16x8 al = WR[c * 1024 + ((1 * 4 + T) * 2 + ks) * 64 + lo];
+                    rh[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, BH[ks], rh[T], 0, 0, 0);
+                    rl[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, BL[ks], rl[T], 0, 0, 0);
+                    rl[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, BH[ks], rl[T], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                q[c][s] = fmaf(fmaf(rl[s >> 2][s & 3], LO, rh[s >> 2][s & 3]), wd1[s], q[c][s]);
+        }
+    }
+
+    float pj[NOUT][NIN];
+#pragma unroll
+    for (int c = 0; c < NOUT; ++c)
+#pragma unroll
+        for (int j = 0; j < NIN; ++j) pj[c][j] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const f32x4 w0 = REC2[kbase(s) + 4 * hq];
+#pragma unroll
+        for (int c = 0; c < NOUT; ++c)
+#pragma unroll
+            for (int j = 0; j < NIN; ++j) pj[c][j] = fmaf(q[c][s], w0[j], pj[c][j]);
+    }
+    float* red = lds + L_RED;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NOUT; ++c)
+#pragma unroll
+        for (int j = 0; j < NIN; ++j) {
+            float v = pj[c][j];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (hq == 0) red[(wave * EMBED_TILE + n) * (NOUT * NIN) + c * NIN + j] = v;
+        }
+    __syncthreads();
+    if (tid < EMBED_TILE && valid) {
+        float sumw = 0.0f;
+        for (int i = 0; i < nn; ++i) sumw += nt.w[i];
+        const float* lin = lds + L_LIN;
+#pragma unroll
+        for (int c = 0; c < NOUT; ++c)
+#pragma unroll
+            for (int j = 0; j < NIN; ++j) {
+                float v = red[(0 * EMBED_TILE + n) * (NOUT * NIN) + c * NIN + j];
+#pragma unroll
+                for (int wv = 1; wv < 4; ++wv) v += red[(wv * EMBED_TILE + n) * (NOUT * NIN) + c * NIN + j];
+                v = fmaf(sumw, lin[4 * c + j], v);
+                if (j < NA) oa[((size_t)row * NOUT + c) * NA + j] = v;
+                else ob[((size_t)row * NOUT + c) * NB + (j - NA)] = v;
+            }
+    }
+}
+
 // LOOP tags the launches made from the closed-loop step so that a profiler lists them apart from
 // the set-up launches (target selector, stand-alone calls); the code is identical.
-template <int NX, int NU, int NY, bool LOOP>
+// H2 selects the split-fp16 matrix path (embed_tile_h2) instead of the fp32 MFMA path.
+template <int NX, int NU, int NY, bool LOOP, bool H2>
 __global__ __launch_bounds__(EMBED_THREADS, 3) void embed_kernel(EmbedArgs a, NodeTable nt) {
     extern __shared__ __align__(16) float lds[];
     int npts = a.npts;
@@ -203,25 +406,37 @@ __global__ __launch_bounds__(EMBED_THREADS, 3) void embed_kernel(EmbedArgs a, No
     const int b = blockIdx.x;
     if (b < a.n_ftiles) {
         if (b * EMBED_TILE >= npts) return;
-        embed_tile<NX, NU, NX>(a.fpack, lds, a.x, a.u, a.A, a.B, b, npts, a.act, a.group, nt);
+        if (H2) embed_tile_h2<NX, NU, NX>(a.fpack, lds, a.x, a.u, a.A, a.B, b, npts, a.act, a.group, nt);
+        else embed_tile<NX, NU, NX>(a.fpack, lds, a.x, a.u, a.A, a.B, b, npts, a.act, a.group, nt);
     } else {
         const int t = b - a.n_ftiles;
         if (t * EMBED_TILE >= npts) return;
-        embed_tile<NX, 0, NY>(a.hpack, lds, a.xc, nullptr, a.C, nullptr, t, npts, a.act, a.group, nt);
+        if (H2) embed_tile_h2<NX, 0, NY>(a.hpack, lds, a.xc, nullptr, a.C, nullptr, t, npts, a.act, a.group, nt);
+        else embed_tile<NX, 0, NY>(a.hpack, lds, a.xc, nullptr, a.C, nullptr, t, npts, a.act, a.group, nt);
     }
 }
 
-template <int NX, int NU, int NY, bool LOOP>
+template <int NX, int NU, int NY, bool LOOP, bool H2>
 static int embed_launch_t(const EmbedArgs& a, const NodeTable& nt, int grid, size_t lds_bytes, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        NMPC_HIP_CHECK(hipFuncSetAttribute((const void*)embed_kernel<NX, NU, NY, LOOP>,
+        NMPC_HIP_CHECK(hipFuncSetAttribute((const void*)embed_kernel<NX, NU, NY, LOOP, H2>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((embed_kernel<NX, NU, NY, LOOP>), dim3(grid), dim3(EMBED_THREADS), lds_bytes, stream, a, nt);
+    hipLaunchKernelGGL((embed_kernel<NX, NU, NY, LOOP, H2>), dim3(grid), dim3(EMBED_THREADS), lds_bytes, stream, a, nt);
     NMPC_HIP_CHECK(hipGetLastError());
     return 0;
+}
+
+// NMPC_EMBED=f32 selects the fp32-MFMA kernel, anything else the split-fp16 kernel
+static bool embed_use_h2() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("NMPC_EMBED");
+        v = (e && std::string(e) == "f32") ? 0 : 1;
+    }
+    return v == 1;
 }
 
 int embed_launch(const ModelDev& m, EmbedArgs a, const NodeTable& nt, hipStream_t stream, bool loop) {
@@ -231,19 +446,22 @@ int embed_launch(const ModelDev& m, EmbedArgs a, const NodeTable& nt, hipStream_
     const bool do_f = a.x && a.u && a.A && a.B, do_h = a.xc && a.C;
     NMPC_REQUIRE(do_f || do_h, "embed: nothing to compute (need x,u,A,B and/or xc,C)");
     const int tiles = (a.npts + EMBED_TILE - 1) / EMBED_TILE;
-    a.fpack = m.fpack; a.hpack = m.hpack;
+    const bool h2 = embed_use_h2();
+    a.fpack = h2 ? m.fpack_h2 : m.fpack; a.hpack = h2 ? m.hpack_h2 : m.hpack;
     a.n_ftiles = do_f ? tiles : 0;
     if (a.group < 1) a.group = 1;
     const int grid = a.n_ftiles + (do_h ? tiles : 0);
     const int nout_max = m.nx > m.ny ? m.nx : m.ny;
     const size_t lds_bytes = sizeof(float) * (4096 + 4096 * nout_max + PK_TAIL);
-#define NMPC_EMBED_CASE(NX_, NU_, NY_)                                                            \
-    if (m.nx == NX_ && m.nu == NU_ && m.ny == NY_)                                                \
-        return loop ? embed_launch_t<NX_, NU_, NY_, true>(a, nt, grid, lds_bytes, stream)         \
-                    : embed_launch_t<NX_, NU_, NY_, false>(a, nt, grid, lds_bytes, stream);
+#define NMPC_EMBED_CASE(NX_, NU_, NY_)                                                                   \
+    if (m.nx == NX_ && m.nu == NU_ && m.ny == NY_) {                                                     \
+        if (h2) return loop ? embed_launch_t<NX_, NU_, NY_, true, true>(a, nt, grid, lds_bytes, stream)  \
+                            : embed_launch_t<NX_, NU_, NY_, false, true>(a, nt, grid, lds_bytes, stream); \
+        return loop ? embed_launch_t<NX_, NU_, NY_, true, false>(a, nt, grid, lds_bytes, stream)         \
+                    : embed_launch_t<NX_, NU_, NY_, false, false>(a, nt, grid, lds_bytes, stream);       \
+    }
     NMPC_EMBED_CASE(2, 1, 1)
     NMPC_EMBED_CASE(3, 1, 1)
-    NMPC_EMBED_CASE(2, 2, 1)
 #undef NMPC_EMBED_CASE
     set_error("embed: no kernel instantiated for nx=%d nu=%d ny=%d", m.nx, m.nu, m.ny);
     return 1;

@@ -48,6 +48,39 @@ static void pack_net(const float* const* p, int n_in, int n_out, std::vector<flo
         for (int j = 0; j < n_in; ++j) out[PK_LIN + 4 * c + j] = lin_w[c * n_in + j];
 }
 
+// Split-fp16 packing: every fragment element W is stored as two halves, Wh = fp16(W) and
+// Wl' = fp16((W - Wh) 2^11).  Fragment of tile T, k-step ks: lane l (row 16T + (l&15), quarter
+// hq = l>>4) holds 8 halves j = 0..7 for the hidden unit 16 (2 ks + (j>>2)) + 4 hq + (j&3), i.e.
+// unit s = 8 ks + j in the kernel's numbering.  Region layout: [plane][T][ks][lane][8 halves].
+static bool pack_net_h2(const float* const* p, int n_in, int n_out, std::vector<float>& out) {
+    std::vector<float> f32;
+    pack_net(p, n_in, n_out, f32);                 // small tables (REC1, REC2, LIN) are shared
+    out = f32;
+    const float *w2 = p[4], *w4 = p[6];
+    const double c2 = 2.0 * 1.4426950408889634074;
+    _Float16* base = reinterpret_cast<_Float16*>(out.data());
+    bool ok = true;
+    auto put = [&](size_t region_floats, int T, int ks, int lane, int j, double w) {
+        if (!(std::fabs(w) < 6.0e4)) ok = false;
+        const _Float16 h = (_Float16)(float)w;
+        const _Float16 l = (_Float16)(float)((w - (double)(float)h) * 2048.0);
+        _Float16* reg = base + 2 * region_floats;
+        reg[((((size_t)0 * 4 + T) * 2 + ks) * 64 + lane) * 8 + j] = h;
+        reg[((((size_t)1 * 4 + T) * 2 + ks) * 64 + lane) * 8 + j] = l;
+    };
+    for (int T = 0; T < 4; ++T)
+        for (int ks = 0; ks < 2; ++ks)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int hq = lane >> 4, r = lane & 15;
+                    const int k = 16 * (2 * ks + (j >> 2)) + 4 * hq + (j & 3);
+                    put(PK_WF, T, ks, lane, j, c2 * (double)w2[(16 * T + r) * HID + k]);
+                    for (int c = 0; c < n_out; ++c)
+                        put(PK_WR + 4096 * c, T, ks, lane, j, (double)w2[k * HID + 16 * T + r] * 4.0 * (double)w4[c * HID + k]);
+                }
+    return ok;
+}
+
 static void eval_net_at_zero(const float* const* p, int n_in, int n_out, int hidden, double* y) {
     std::vector<double> t1(hidden), t2(hidden);
     for (int k = 0; k < hidden; ++k) t1[k] = std::tanh((double)p[3][k]);
@@ -92,6 +125,12 @@ extern "C" int nmpc_model_create(nmpc_model** out, int nx, int nu, int ny, int h
     pack_net(hn, nx, ny, buf);
     NMPC_HIP_CHECK(hipMalloc(&m->d.hpack, PACK_FLOATS * sizeof(float)));
     NMPC_HIP_CHECK(hipMemcpy(m->d.hpack, buf.data(), PACK_FLOATS * sizeof(float), hipMemcpyHostToDevice));
+    NMPC_REQUIRE(pack_net_h2(fn, nx + nu, nx, buf), "nmpc_model_create: f-net weights exceed the fp16 range");
+    NMPC_HIP_CHECK(hipMalloc(&m->d.fpack_h2, PACK_FLOATS * sizeof(float)));
+    NMPC_HIP_CHECK(hipMemcpy(m->d.fpack_h2, buf.data(), PACK_FLOATS * sizeof(float), hipMemcpyHostToDevice));
+    NMPC_REQUIRE(pack_net_h2(hn, nx, ny, buf), "nmpc_model_create: h-net weights exceed the fp16 range");
+    NMPC_HIP_CHECK(hipMalloc(&m->d.hpack_h2, PACK_FLOATS * sizeof(float)));
+    NMPC_HIP_CHECK(hipMemcpy(m->d.hpack_h2, buf.data(), PACK_FLOATS * sizeof(float), hipMemcpyHostToDevice));
     eval_net_at_zero(fn, nx + nu, nx, hidden, m->d.f0);
     eval_net_at_zero(hn, nx, ny, hidden, m->d.h0);
     auto upload_plain = [&](const float* const* p, int n_in, int n_out, float** dst) -> int {
@@ -114,6 +153,8 @@ extern "C" void nmpc_model_destroy(nmpc_model* m) {
     if (!m) return;
     if (m->d.fpack) (void)hipFree(m->d.fpack);
     if (m->d.hpack) (void)hipFree(m->d.hpack);
+    if (m->d.fpack_h2) (void)hipFree(m->d.fpack_h2);
+    if (m->d.hpack_h2) (void)hipFree(m->d.hpack_h2);
     if (m->d.enc) (void)hipFree(m->d.enc);
     if (m->d.hplain) (void)hipFree(m->d.hplain);
     delete m;
