@@ -178,6 +178,7 @@ struct MpcQpArgs {
     const double *lA, *lB, *lC, *x0, *ymeas, *Xs, *Us;
     double *Ge, *Fe, *Le, *hv, *u, *eps, *xpred;
     int* status;
+    unsigned long long* stamps;   // optional diagnostics: 8 clock values per problem
     MpcConst c;
 };
 
@@ -190,6 +191,8 @@ __global__ void mpc_qp_kernel(MpcQpArgs a) {
     const int Nc = a.c.Nc, n = Nc + 1, mt = 4 * Nc + 2;
     MpcLds L;
     L.carve(mpc_lds + (size_t)g * mpc_lds_doubles(Nc, NX), Nc, NX);
+    unsigned long long* st = a.stamps ? a.stamps + (size_t)prob * 8 : nullptr;
+    if (st && gl == 0) st[0] = __builtin_amdgcn_s_memtime();
     for (int e = gl; e < Nc * NX * NX; e += GS) L.Ak[e] = a.lA[(size_t)prob * Nc * NX * NX + e];
     for (int e = gl; e < Nc * NX; e += GS) {
         L.Bk[e] = a.lB[(size_t)prob * Nc * NX + e];
@@ -200,19 +203,21 @@ __global__ void mpc_qp_kernel(MpcQpArgs a) {
     for (int e = gl; e < NX; e += GS) L.x0[e] = a.x0[(size_t)prob * NX + e];
     g_sync();
     mpc_assemble<GS, NX>(a.c, L, a.ymeas[prob], gl);
+    if (st && gl == 0) st[1] = __builtin_amdgcn_s_memtime();
     if (a.Ge) for (int e = gl; e < n * n; e += GS) a.Ge[(size_t)prob * n * n + e] = L.qp.Lm[e];
     if (a.Fe) for (int e = gl; e < n; e += GS) a.Fe[(size_t)prob * n + e] = L.qp.xt[e];
     if (a.Le) for (int e = gl; e < mt * n; e += GS) a.Le[(size_t)prob * mt * n + e] = L.qp.Nt[(e % n) * mt + e / n];
     if (a.hv) for (int e = gl; e < mt; e += GS) a.hv[(size_t)prob * mt + e] = L.qp.hv[e];
     if (!a.u && !a.xpred && !a.eps) return;
-    const int st = gi_solve<GS, MPL>(n, mt, 0, L.qp, nullptr, nullptr);
+    const int stt = gi_solve<GS, MPL>(n, mt, 0, L.qp, nullptr, nullptr, st ? st + 2 : nullptr);
     const double epsv = L.qp.xt[Nc];
     mpc_predict<GS, NX>(a.c, L, gl);
+    if (st && gl == 0) st[7] = __builtin_amdgcn_s_memtime();
     if (a.u) for (int e = gl; e < Nc; e += GS) a.u[(size_t)prob * Nc + e] = L.qp.xt[e];
     if (a.xpred) for (int e = gl; e < Nc * NX; e += GS) a.xpred[(size_t)prob * Nc * NX + e] = L.xi[e];
     if (gl == 0) {
         if (a.eps) a.eps[prob] = epsv;
-        if (a.status) a.status[prob] = st;
+        if (a.status) a.status[prob] = stt;
     }
 }
 
@@ -549,6 +554,8 @@ extern "C" int nmpc_mpc_qp(int nb, int Nc, int nx, const double* list_A, const d
     a.nb = nb; a.nx = nx; a.lA = list_A; a.lB = list_B; a.lC = list_C; a.x0 = x0; a.ymeas = y_meas; a.Xs = Xs; a.Us = Us;
     a.Ge = Ge; a.Fe = Fe; a.Le = Le; a.hv = hv; a.u = u; a.eps = eps; a.xpred = xpred; a.status = status;
     fill_const(a.c, Nc, nx, Q, R, rho, u_min, u_max, y_min, y_max, f0, h0);
+    // diagnostics: NMPC_MPC_STAMPS=<device pointer, hex> receives 8 clock stamps per problem
+    if (const char* e = getenv("NMPC_MPC_STAMPS")) a.stamps = (unsigned long long*)strtoull(e, nullptr, 16);
     return dispatch_mpc_qp(a, g, (hipStream_t)stream);
 }
 

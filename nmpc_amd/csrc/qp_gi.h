@@ -97,8 +97,11 @@ struct QPWork {
 // (equalities first), hv = right-hand sides, xt = q.  On exit: xt = optimum z; if lam != null,
 // lam[i] = multiplier of row i.  Requires n <= GS and mt <= GS*MPL.
 // Returns 0 ok, 1 iteration limit, 2 infeasible, 3 P not positive definite.
+// `stamp` (optional, diagnostics): 5 clock values [after chol, after transform, after slack init,
+// after the active-set loop, at exit] written by the group's first lane.
 template <int GS, int MPL>
-__device__ int gi_solve(int n, int mt, int meq, QPWork& w, double* lam, int* iters_out) {
+__device__ int gi_solve(int n, int mt, int meq, QPWork& w, double* lam, int* iters_out,
+                        unsigned long long* stamp = nullptr) {
     const int gl = (threadIdx.x & 63) & (GS - 1);
     double *Lm = w.Lm, *Nt = w.Nt, *hv = w.hv, *xt = w.xt, *Lw = w.Lw;
     int status = 0, iters = 0;
@@ -107,6 +110,7 @@ __device__ int gi_solve(int n, int mt, int meq, QPWork& w, double* lam, int* ite
         if (iters_out) *iters_out = 0;
         return 3;
     }
+    if (stamp && gl == 0) stamp[0] = __builtin_amdgcn_s_memtime();
     // nt_i = L^-1 (-g_i) for every constraint, zt_unc = -L^-1 q  (one column per lane)
     for (int i = gl; i <= mt; i += GS) {
         double* col = i < mt ? Nt + i : xt;
@@ -118,6 +122,7 @@ __device__ int gi_solve(int n, int mt, int meq, QPWork& w, double* lam, int* ite
         }
     }
     g_sync();
+    if (stamp && gl == 0) stamp[1] = __builtin_amdgcn_s_memtime();
     double s[MPL], sgn[MPL];
     unsigned amask = 0;
 #pragma unroll
@@ -130,6 +135,7 @@ __device__ int gi_solve(int n, int mt, int meq, QPWork& w, double* lam, int* ite
         }
         s[sl] = v; sgn[sl] = 1.0;
     }
+    if (stamp && gl == 0) stamp[2] = __builtin_amdgcn_s_memtime();
     int q = 0, eq_next = 0;
     double lamj = 0.0;        // multiplier of working-set position gl
     int wj = -1;              // constraint index at working-set position gl
@@ -268,6 +274,7 @@ __device__ int gi_solve(int n, int mt, int meq, QPWork& w, double* lam, int* ite
         }
         if (status) break;
     }
+    if (stamp && gl == 0) stamp[3] = __builtin_amdgcn_s_memtime();
     // z:  L' z = zt_unc + Nt_W lam
     g_sync();
     if (gl < q) { w.lamW[gl] = lamj; w.Wl[gl] = wj; }
@@ -301,6 +308,7 @@ __device__ int gi_solve(int n, int mt, int meq, QPWork& w, double* lam, int* ite
         }
     }
     g_sync();
+    if (stamp && gl == 0) stamp[4] = __builtin_amdgcn_s_memtime();
     if (iters_out) *iters_out = iters;
     return status;
 }
