@@ -148,7 +148,8 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = ctrl.profile_read()
     ctrl.profile(False)
-    if ctrl.qp_failures():
+    qp_fail, qp_solves, qp_iters = ctrl.stats()
+    if qp_fail:
         raise SystemExit("QP failures in the closed loop: result invalid")
 
     elapsed_max = shard.reduce_stats([elapsed], "max")[0]
@@ -182,6 +183,7 @@ def main():
                        "batch_per_gpu": B, "Nc": NC, "parallelism": "dp%d (independent shards)" % world},
             "p50_step_latency_ms": None,
             "mean_lpv_passes_per_step": tot_passes / (world * B * K),
+            "mean_qp_active_set_iterations": qp_iters / max(qp_solves, 1),
             "kernel_ms_per_step": {k: prof[k][1] / K for k in prof},
             "target_selector_s": t_targets, "final_gather_s": t_gather,
             "median_abs_tracking_error": track,

@@ -129,9 +129,9 @@ int nmpc_ctrl_reset(nmpc_ctrl* c, const double* x0n, double u0n, const double* p
 int nmpc_ctrl_run(nmpc_ctrl* c, int k0, int nsteps, const double* Xs, const double* Us, const double* noise,
                   double* x_log, double* u_log, double* e_log, double* y_log, double* y_est_log,
                   int* lpv_counter, double* plan_log, void* stream);
-/* qp_fail[1] (host): number of (controller, pass) QP solves so far that did not return status 0.
- * Synchronises the stream. */
-int nmpc_ctrl_stats(nmpc_ctrl* c, long long* qp_fail, void* stream);
+/* stats[3] (host): [0] (controller, pass) QP solves since reset that did not return status 0,
+ * [1] QP solves, [2] active-set iterations summed over them.  Synchronises the stream. */
+int nmpc_ctrl_stats(nmpc_ctrl* c, long long* stats, void* stream);
 
 /* Optional per-kernel timing of a controller's launches with HIP events recorded on the stream the
  * kernels are launched on.  nmpc_ctrl_profile(c, 1) makes later nmpc_ctrl_run calls bracket every

@@ -209,7 +209,8 @@ __global__ void mpc_qp_kernel(MpcQpArgs a) {
     if (a.Le) for (int e = gl; e < mt * n; e += GS) a.Le[(size_t)prob * mt * n + e] = L.qp.Nt[(e % n) * mt + e / n];
     if (a.hv) for (int e = gl; e < mt; e += GS) a.hv[(size_t)prob * mt + e] = L.qp.hv[e];
     if (!a.u && !a.xpred && !a.eps) return;
-    const int stt = gi_solve<GS, MPL>(n, mt, 0, L.qp, nullptr, nullptr, st ? st + 2 : nullptr);
+    const int stt = (GS == 64 && n <= 16) ? gi_solve<GS, MPL, (GS == 64 ? 16 : 0)>(n, mt, 0, L.qp, nullptr, nullptr, st ? st + 2 : nullptr)
+                                          : gi_solve<GS, MPL>(n, mt, 0, L.qp, nullptr, nullptr, st ? st + 2 : nullptr);
     const double epsv = L.qp.xt[Nc];
     mpc_predict<GS, NX>(a.c, L, gl);
     if (st && gl == 0) st[7] = __builtin_amdgcn_s_memtime();
@@ -231,7 +232,8 @@ struct CtrlDev {
     // state (fp64)
     double *x0n, *xpred, *uplan, *ymeas, *xp, *uhist, *yhist, *eps;
     int *cnt, *act, *nact;
-    unsigned long long* qp_fail;
+    unsigned long long* qp_fail;   // failed solves
+    unsigned* qp_stat;             // [B][2]: solves, active-set iterations per controller
     // fp32 scheduling points and embedding outputs
     float *xs32, *us32, *xc32, *A32, *B32, *C32;
     const float *enc, *hplain;
@@ -269,7 +271,9 @@ __global__ void mpc_solve_kernel(CtrlDev d, RunPtrs rp, int it, int k) {
     for (int e = gl; e < NX; e += GS) L.x0[e] = d.x0n[(size_t)b * NX + e];
     g_sync();
     mpc_assemble<GS, NX>(d.c, L, d.ymeas[b], gl);
-    const int st = gi_solve<GS, MPL>(n, mt, 0, L.qp, nullptr, nullptr);
+    int qp_it = 0;
+    const int st = (GS == 64 && n <= 16) ? gi_solve<GS, MPL, (GS == 64 ? 16 : 0)>(n, mt, 0, L.qp, nullptr, &qp_it)
+                                         : gi_solve<GS, MPL>(n, mt, 0, L.qp, nullptr, &qp_it);
     const double epsv = L.qp.xt[Nc];
     mpc_predict<GS, NX>(d.c, L, gl);
     double du = 0.0;
@@ -291,6 +295,8 @@ __global__ void mpc_solve_kernel(CtrlDev d, RunPtrs rp, int it, int k) {
         d.eps[b] = epsv;
         d.cnt[b] = it + 1;
         if (st != 0) atomicAdd(d.qp_fail, 1ull);
+        d.qp_stat[2 * b] += 1u;                 // per-controller tallies: no shared-address atomics
+        d.qp_stat[2 * b + 1] += (unsigned)qp_it;
         if (it + 1 < d.maxit && !(sqrt(du) < d.tol)) {
             const int pos = atomicAdd(&d.nact[it + 1], 1);
             d.act[(size_t)(it + 1) * d.B + pos] = b;
@@ -448,6 +454,7 @@ __global__ void reset_kernel(CtrlDev d, double u0n, double x0a, double x0b, doub
     }
     for (int i = 0; i < Nc; ++i) { d.uplan[(size_t)b * Nc + i] = u0n; d.us32[(size_t)b * Nc + i] = (float)u0n; }
     d.ymeas[b] = 0.0; d.eps[b] = 0.0; d.cnt[b] = 0;
+    d.qp_stat[2 * b] = 0u; d.qp_stat[2 * b + 1] = 0u;
     d.xp[2 * b] = pw; d.xp[2 * b + 1] = pth;
     for (int j = 0; j < d.na; ++j) d.uhist[(size_t)b * d.na + j] = 0.0;
     for (int j = 0; j < d.nyh; ++j) d.yhist[(size_t)b * d.nyh + j] = 0.0;
@@ -624,7 +631,7 @@ extern "C" int nmpc_ctrl_create(nmpc_ctrl** out, const nmpc_model* m, const nmpc
     rc |= alloc((void**)&d.xp, sb * 2 * 8); rc |= alloc((void**)&d.uhist, sb * d.na * 8);
     rc |= alloc((void**)&d.yhist, sb * d.nyh * 8); rc |= alloc((void**)&d.eps, sb * 8);
     rc |= alloc((void**)&d.cnt, sb * 4); rc |= alloc((void**)&d.act, sb * (d.maxit + 1) * 4);
-    rc |= alloc((void**)&d.nact, (d.maxit + 2) * 4); rc |= alloc((void**)&d.qp_fail, 8);
+    rc |= alloc((void**)&d.nact, (d.maxit + 2) * 4); rc |= alloc((void**)&d.qp_fail, 8); rc |= alloc((void**)&d.qp_stat, sb * 8);
     rc |= alloc((void**)&d.xs32, sb * Nc * nx * 4); rc |= alloc((void**)&d.us32, sb * Nc * 4);
     rc |= alloc((void**)&d.xc32, sb * Nc * nx * 4); rc |= alloc((void**)&d.A32, sb * Nc * nx * nx * 4);
     rc |= alloc((void**)&d.B32, sb * Nc * nx * 4); rc |= alloc((void**)&d.C32, sb * Nc * nx * 4);
@@ -712,8 +719,11 @@ extern "C" int nmpc_ctrl_profile_read(nmpc_ctrl* c, int* launches, double* total
 extern "C" int nmpc_ctrl_stats(nmpc_ctrl* c, long long* qp_fail, void* stream) {
     NMPC_REQUIRE(c && qp_fail, "nmpc_ctrl_stats: null argument");
     unsigned long long v = 0;
+    std::vector<unsigned> st(2 * (size_t)c->d.B);
     NMPC_HIP_CHECK(hipMemcpyAsync(&v, c->d.qp_fail, 8, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    NMPC_HIP_CHECK(hipMemcpyAsync(st.data(), c->d.qp_stat, st.size() * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
     NMPC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
-    *qp_fail = (long long)v;
+    qp_fail[0] = (long long)v; qp_fail[1] = 0; qp_fail[2] = 0;
+    for (int b = 0; b < c->d.B; ++b) { qp_fail[1] += st[2 * b]; qp_fail[2] += st[2 * b + 1]; }
     return 0;
 }

@@ -41,7 +41,8 @@ __global__ void qp_kernel(QPArgs a) {
     for (int e = gl; e < meq; e += GS) w.hv[e] = a.beq[(size_t)prob * meq + e];
     for (int e = gl; e < a.m; e += GS) w.hv[meq + e] = a.h[(size_t)prob * a.m + e];
     int it = 0;
-    const int st = gi_solve<GS, MPL>(n, mt, meq, w, lam, &it);
+    const int st = (GS == 64 && n <= 16) ? gi_solve<GS, MPL, (GS == 64 ? 16 : 0)>(n, mt, meq, w, lam, &it)
+                                         : gi_solve<GS, MPL>(n, mt, meq, w, lam, &it);
     for (int e = gl; e < n; e += GS) a.z[(size_t)prob * n + e] = w.xt[e];
     if (a.lambda)
         for (int e = gl; e < mt; e += GS) a.lambda[(size_t)prob * mt + e] = lam[e];

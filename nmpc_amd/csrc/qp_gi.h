@@ -80,6 +80,88 @@ __device__ __forceinline__ bool g_chol(double* M, int nn, int ld, double* invd, 
     return true;
 }
 
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)b, lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// 1/sqrt(d) to full fp64 accuracy: hardware estimate + two Newton steps
+__device__ __forceinline__ double rsqrt_d(double d) {
+    double r = __builtin_amdgcn_rsq(d);
+    r = r * fma(-0.5 * d * r, r, 1.5);
+    r = r * fma(-0.5 * d * r, r, 1.5);
+    return r;
+}
+
+// Whole-wave (GS = 64) Cholesky and transform for n <= NMAX with lane i holding row i of the
+// matrix in registers: the pivot column travels through v_readlane (an SGPR broadcast), so no LDS
+// round trip or barrier sits on the critical path.  On exit Lm holds L (row-major), invd the
+// inverse diagonal, and every column of Nt as well as xt has been replaced by L^-1 (-column).
+template <int NMAX, int MPL>
+__device__ __forceinline__ bool chol_transform_rows(double* Lm, double* Nt, double* xt, double* invd, int n, int mt) {
+    const int lane = threadIdx.x & 63;
+    double row[NMAX], inv[NMAX];
+#pragma unroll
+    for (int c = 0; c < NMAX; ++c) row[c] = (lane < n && c <= lane && c < n) ? Lm[lane * n + c] : 0.0;
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j) {
+        if (j < n) {
+            const double d = readlane_d(row[j], j);
+            if (!(d > 0.0)) ok = false;
+            inv[j] = rsqrt_d(d > 0.0 ? d : 1.0);
+            row[j] *= inv[j];                      // lane j: sqrt(d); lanes i > j: L[i][j]
+#pragma unroll
+            for (int c = j + 1; c < NMAX; ++c)
+                if (c < n) {
+                    const double lcj = readlane_d(row[j], c);
+                    if (lane >= c) row[c] = fma(-row[j], lcj, row[c]);
+                }
+        } else {
+            inv[j] = 0.0;
+        }
+    }
+    if (!ok) return false;
+    if (lane < n) {
+#pragma unroll
+        for (int c = 0; c < NMAX; ++c)
+            if (c <= lane && c < n) Lm[lane * n + c] = row[c];
+    }
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j)
+        if (j < n && lane == 0) invd[j] = inv[j];
+    // forward substitution of every column (constraint normals and q), one column per lane and slot
+#pragma unroll
+    for (int sl = 0; sl <= MPL; ++sl) {
+        const int cid = lane + 64 * sl;
+        if (64 * sl <= mt) {                       // wave-uniform
+            const bool act = cid <= mt;
+            double* col = cid < mt ? Nt + cid : xt;
+            const int st = cid < mt ? mt : 1;
+            double y[NMAX];
+#pragma unroll
+            for (int k = 0; k < NMAX; ++k) {
+                if (k < n) {
+                    double v = act ? -col[k * st] : 0.0;
+#pragma unroll
+                    for (int l = 0; l < k; ++l) v = fma(-readlane_d(row[l], k), y[l], v);
+                    y[k] = v * inv[k];
+                } else {
+                    y[k] = 0.0;
+                }
+            }
+            if (act) {
+#pragma unroll
+                for (int k = 0; k < NMAX; ++k)
+                    if (k < n) col[k * st] = y[k];
+            }
+        }
+    }
+    return true;
+}
+
 // LDS footprint in doubles of one problem (ints of the working set included, rounded up)
 __host__ __device__ inline int qp_lds_doubles(int n, int mt) { return 2 * n * n + n * mt + mt + 8 * n; }
 
@@ -99,26 +181,36 @@ struct QPWork {
 // Returns 0 ok, 1 iteration limit, 2 infeasible, 3 P not positive definite.
 // `stamp` (optional, diagnostics): 5 clock values [after chol, after transform, after slack init,
 // after the active-set loop, at exit] written by the group's first lane.
-template <int GS, int MPL>
+// NMAX > 0 (only with GS = 64): n <= NMAX, Cholesky and transform run in registers.
+template <int GS, int MPL, int NMAX = 0>
 __device__ int gi_solve(int n, int mt, int meq, QPWork& w, double* lam, int* iters_out,
                         unsigned long long* stamp = nullptr) {
     const int gl = (threadIdx.x & 63) & (GS - 1);
     double *Lm = w.Lm, *Nt = w.Nt, *hv = w.hv, *xt = w.xt, *Lw = w.Lw;
     int status = 0, iters = 0;
     g_sync();
-    if (!g_chol<GS>(Lm, n, n, w.invdL, gl)) {
-        if (iters_out) *iters_out = 0;
-        return 3;
-    }
-    if (stamp && gl == 0) stamp[0] = __builtin_amdgcn_s_memtime();
-    // nt_i = L^-1 (-g_i) for every constraint, zt_unc = -L^-1 q  (one column per lane)
-    for (int i = gl; i <= mt; i += GS) {
-        double* col = i < mt ? Nt + i : xt;
-        const int st = i < mt ? mt : 1;
-        for (int k = 0; k < n; ++k) {
-            double v = -col[k * st];
-            for (int l = 0; l < k; ++l) v -= Lm[k * n + l] * col[l * st];
-            col[k * st] = v * w.invdL[k];
+    if constexpr (GS == 64 && NMAX > 0) {
+        const bool ok = chol_transform_rows<NMAX, MPL>(Lm, Nt, xt, w.invdL, n, mt);
+        if (stamp && gl == 0) stamp[0] = __builtin_amdgcn_s_memtime();
+        if (!ok) {
+            if (iters_out) *iters_out = 0;
+            return 3;
+        }
+    } else {
+        if (!g_chol<GS>(Lm, n, n, w.invdL, gl)) {
+            if (iters_out) *iters_out = 0;
+            return 3;
+        }
+        if (stamp && gl == 0) stamp[0] = __builtin_amdgcn_s_memtime();
+        // nt_i = L^-1 (-g_i) for every constraint, zt_unc = -L^-1 q  (one column per lane)
+        for (int i = gl; i <= mt; i += GS) {
+            double* col = i < mt ? Nt + i : xt;
+            const int st = i < mt ? mt : 1;
+            for (int k = 0; k < n; ++k) {
+                double v = -col[k * st];
+                for (int l = 0; l < k; ++l) v -= Lm[k * n + l] * col[l * st];
+                col[k * st] = v * w.invdL[k];
+            }
         }
     }
     g_sync();

@@ -144,11 +144,15 @@ class Controller:
             check(lib().nmpc_ctrl_profile_read(self.handle, n, ms, current_stream()), "nmpc_ctrl_profile_read")
         return {k: (int(n[i]), float(ms[i])) for i, k in enumerate(("embed", "solve", "plant"))}
 
-    def qp_failures(self):
-        v = ctypes.c_longlong(0)
+    def stats(self):
+        """(failed QP solves, QP solves, active-set iterations) since reset; synchronises."""
+        v = (ctypes.c_longlong * 3)()
         with torch.cuda.device(self.encoder.device):
-            check(lib().nmpc_ctrl_stats(self.handle, ctypes.byref(v), current_stream()), "nmpc_ctrl_stats")
-        return int(v.value)
+            check(lib().nmpc_ctrl_stats(self.handle, v, current_stream()), "nmpc_ctrl_stats")
+        return int(v[0]), int(v[1]), int(v[2])
+
+    def qp_failures(self):
+        return self.stats()[0]
 
 
 def output_NMPC_linear(system, encoder, u_min, u_max, y_min, y_max, x0, Q, R, dt, dlam, stages, y_reference_list,
