@@ -35,8 +35,9 @@ constexpr int PK_WR = 4096;       // [4][4][4][64][4] reverse A-fragments of (4 
 constexpr int PK_REC1 = 20480;    // [64][4] {c2*b0[k], c2*b2[k], 0, 0}
 constexpr int PK_REC2 = 20736;    // [64][4] W0[k][0..3] (zero padded)
 constexpr int PK_LIN = 20992;     // [4][4]  W_lin[c][j] (zero padded)
-constexpr int PACK_FLOATS = 21008;
-constexpr int PK_TAIL = PACK_FLOATS - PK_REC1;   // REC1 + REC2 + LIN, contiguous
+constexpr int PK_J0 = 21008;      // [4][4]  Jacobian of the nonlinear branch at the origin, W4 D2 W2 D1 W0 (fp64-evaluated)
+constexpr int PACK_FLOATS = 21024;
+constexpr int PK_TAIL = PACK_FLOATS - PK_REC1;   // REC1 + REC2 + LIN + J0, contiguous
 
 // Device-resident packed networks.
 struct ModelDev {

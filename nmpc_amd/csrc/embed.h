@@ -8,8 +8,12 @@ namespace nmpc {
 constexpr int EMBED_THREADS = 256;
 constexpr int EMBED_TILE = 16;      // scheduling points per workgroup
 
+// Quadrature nodes.  Callers fill n, lam, w; embed_launch moves nodes at lambda = 0 (where the
+// Jacobian is a constant of the net) out of the table into w_zero and sets w_sum.
 struct NodeTable {
     int n;
+    float w_zero;   // total weight of the nodes at lambda = 0
+    float w_sum;    // total weight of all nodes (multiplies the linear branch)
     float lam[NMPC_MAX_NODES];
     float w[NMPC_MAX_NODES];
 };

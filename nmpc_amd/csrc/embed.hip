@@ -179,8 +179,8 @@ __device__ __forceinline__ void embed_tile(const float* __restrict__ pack, float
         }
     __syncthreads();
     if (tid < EMBED_TILE && valid) {
-        float sumw = 0.0f;
-        for (int i = 0; i < nn; ++i) sumw += nt.w[i];
+        const float sumw = nt.w_sum, wz = nt.w_zero;
+        const float* j0 = lds + L_LIN + 16;
         const float* lin = lds + L_LIN;
 #pragma unroll
         for (int c = 0; c < NOUT; ++c)
@@ -189,7 +189,7 @@ __device__ __forceinline__ void embed_tile(const float* __restrict__ pack, float
                 float v = red[(0 * EMBED_TILE + n) * (NOUT * NIN) + c * NIN + j];
 #pragma unroll
                 for (int wv = 1; wv < 4; ++wv) v += red[(wv * EMBED_TILE + n) * (NOUT * NIN) + c * NIN + j];
-                v = fmaf(sumw, lin[4 * c + j], v);
+                v = fmaf(sumw, lin[4 * c + j], fmaf(wz, j0[4 * c + j], v));
                 if (j < NA) oa[((size_t)row * NOUT + c) * NA + j] = v;
                 else ob[((size_t)row * NOUT + c) * NB + (j - NA)] = v;
             }
@@ -213,11 +213,13 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void split_pair(float a, float b, unsigned& H, unsigned& L) {
-    const float ah = __uint_as_float(__float_as_uint(a) & 0xFFFFE000u);
-    const float bh = __uint_as_float(__float_as_uint(b) & 0xFFFFE000u);
-    const float al = (a - ah) * 2048.0f, bl = (b - bh) * 2048.0f;
-    H = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ah, bh));
-    L = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(al, bl));
+    // H = the pair truncated to fp16; L = the fp16-rounded remainders a - float(H.lo), b - float(H.hi), each
+    // formed by one mixed-precision fma (fp16 * -1.0 + fp32, exact before the final rounding).
+    H = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(H), "v"(a));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(H), "v"(b));
+    L = l;
 }
 
 // 16 fp32 values (unit order) -> B fragments of the two k-steps, high and low planes
@@ -274,7 +276,6 @@ __device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, fl
     for (int j = 0; j < NB; ++j) z[NA + j] = pb[(size_t)row * NB + j];
 
     constexpr float C2 = 2.8853900817779268f;
-    constexpr float LO = 1.0f / 2048.0f;
     float g[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
@@ -292,63 +293,69 @@ __device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, fl
 
     const int nn = nt.n;
     const int n0 = (nn * wave) >> 2, n1 = (nn * (wave + 1)) >> 2;
+    // Activation math with e = 2^-a (a = c2 * preactivation), r = 1/(1 + e) in [0, 1]:
+    //   tanh = 2 r - 1,  (1 - tanh^2) / 4 = r - r^2.  e = inf gives r = 0 and e = 0 gives r = 1, both exact
+    //   limits; errors are absolute (~1 ulp of r).
+    // Products: W x = Wh (xh + xl) + Wl xh, three fp16 MFMAs into one fp32 accumulator (Wl, xl: the fp16
+    // remainders, mostly subnormal, absolute resolution 2^-24).
+    float b0[16];
+    f32x4 b2[4];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const f32x4 rec = REC1[kbase(s) + 4 * hq];
+        b0[s] = rec[0];
+        b2[s >> 2][s & 3] = rec[1];
+    }
     for (int node = n0; node < n1; ++node) {
         const float lam = nt.lam[node];
         const float w4 = 4.0f * nt.w[node];
-        int lo = lane, ho = 4 * hq;
-        asm volatile("" : "+v"(lo), "+v"(ho));
+        int lo = lane;
+        asm volatile("" : "+v"(lo));
         float t1[16], wd1[16];
-        f32x4 acch[4], accl[4];
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const f32x4 r1 = REC1[kbase(s) + ho];
-            float er, r;
-            tanh_parts(fmaf(lam, g[s], r1[0]), er, r);
-            t1[s] = fmaf(-2.0f, r, 1.0f);
-            wd1[s] = (w4 * er) * r;
-            acch[s >> 2][s & 3] = r1[1];
-            accl[s >> 2][s & 3] = 0.0f;
+            const float a = fmaf(lam, g[s], b0[s]);
+            const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-a));
+            t1[s] = fmaf(2.0f, r, -1.0f);
+            wd1[s] = w4 * fmaf(-r, r, r);          // w * (1 - t1^2)
         }
         f16x8 BH[2], BL[2];
         split16(t1, BH, BL);
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc[4];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
             for (int T = 0; T < 4; ++T) {
                 const f16x8 ah = WF[((0 * 4 + T) * 2 + ks) * 64 + lo];
                 const f16x8 al = WF[((1 * 4 + T) * 2 + ks) * 64 + lo];
-                acch[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, BH[ks], acch[T], 0, 0, 0);
-                accl[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, BL[ks], accl[T], 0, 0, 0);
-                accl[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, BH[ks], accl[T], 0, 0, 0);
+                acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, BH[ks], ks == 0 ? b2[T] : acc[T], 0, 0, 0);
+                acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, BL[ks], acc[T], 0, 0, 0);
+                acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, BH[ks], acc[T], 0, 0, 0);
             }
         }
-        float d2q[16];
+        float d2q[16];                             // (1 - t2^2) / 4
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            float er, r;
-            tanh_parts(fmaf(accl[s >> 2][s & 3], LO, acch[s >> 2][s & 3]), er, r);
-            d2q[s] = er * r;
+            const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-acc[s >> 2][s & 3]));
+            d2q[s] = fmaf(-r, r, r);
         }
         split16(d2q, BH, BL);
 #pragma unroll
         for (int c = 0; c < NOUT; ++c) {
-            f32x4 rh[4], rl[4];
-#pragma unroll
-            for (int T = 0; T < 4; ++T) { rh[T] = f32x4{0.f, 0.f, 0.f, 0.f}; rl[T] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
                 for (int T = 0; T < 4; ++T) {
                     const f16x8 ah = WR[c * 1024 + ((0 * 4 + T) * 2 + ks) * 64 + lo];
                     const f16x8 al = WR[c * 1024 + ((1 * 4 + T) * 2 + ks) * 64 + lo];
-                    rh[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, BH[ks], rh[T], 0, 0, 0);
-                    rl[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, BL[ks], rl[T], 0, 0, 0);
-                    rl[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, BH[ks], rl[T], 0, 0, 0);
+                    acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, BH[ks], ks == 0 ? zero4 : acc[T], 0, 0, 0);
+                    acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, BL[ks], acc[T], 0, 0, 0);
+                    acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, BH[ks], acc[T], 0, 0, 0);
                 }
             }
 #pragma unroll
-            for (int s = 0; s < 16; ++s)
-                q[c][s] = fmaf(fmaf(rl[s >> 2][s & 3], LO, rh[s >> 2][s & 3]), wd1[s], q[c][s]);
+            for (int s = 0; s < 16; ++s) q[c][s] = fmaf(acc[s >> 2][s & 3], wd1[s], q[c][s]);
         }
     }
 
@@ -378,8 +385,8 @@ __device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, fl
         }
     __syncthreads();
     if (tid < EMBED_TILE && valid) {
-        float sumw = 0.0f;
-        for (int i = 0; i < nn; ++i) sumw += nt.w[i];
+        const float sumw = nt.w_sum, wz = nt.w_zero;
+        const float* j0 = lds + L_LIN + 16;
         const float* lin = lds + L_LIN;
 #pragma unroll
         for (int c = 0; c < NOUT; ++c)
@@ -388,7 +395,7 @@ __device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, fl
                 float v = red[(0 * EMBED_TILE + n) * (NOUT * NIN) + c * NIN + j];
 #pragma unroll
                 for (int wv = 1; wv < 4; ++wv) v += red[(wv * EMBED_TILE + n) * (NOUT * NIN) + c * NIN + j];
-                v = fmaf(sumw, lin[4 * c + j], v);
+                v = fmaf(sumw, lin[4 * c + j], fmaf(wz, j0[4 * c + j], v));
                 if (j < NA) oa[((size_t)row * NOUT + c) * NA + j] = v;
                 else ob[((size_t)row * NOUT + c) * NB + (j - NA)] = v;
             }
@@ -439,8 +446,14 @@ static bool embed_use_h2() {
     return v == 1;
 }
 
-int embed_launch(const ModelDev& m, EmbedArgs a, const NodeTable& nt, hipStream_t stream, bool loop) {
-    NMPC_REQUIRE(nt.n >= 1 && nt.n <= NMPC_MAX_NODES, "embed: node count %d out of range", nt.n);
+int embed_launch(const ModelDev& m, EmbedArgs a, const NodeTable& nodes, hipStream_t stream, bool loop) {
+    NMPC_REQUIRE(nodes.n >= 1 && nodes.n <= NMPC_MAX_NODES, "embed: node count %d out of range", nodes.n);
+    NodeTable nt{};
+    for (int i = 0; i < nodes.n; ++i) {
+        nt.w_sum += nodes.w[i];
+        if (nodes.lam[i] == 0.0f) { nt.w_zero += nodes.w[i]; continue; }
+        nt.lam[nt.n] = nodes.lam[i]; nt.w[nt.n] = nodes.w[i]; ++nt.n;
+    }
     NMPC_REQUIRE(a.npts >= 0, "embed: negative point count");
     if (a.npts == 0) return 0;
     const bool do_f = a.x && a.u && a.A && a.B, do_h = a.xc && a.C;

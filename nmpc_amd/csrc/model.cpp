@@ -46,6 +46,27 @@ static void pack_net(const float* const* p, int n_in, int n_out, std::vector<flo
     }
     for (int c = 0; c < n_out; ++c)
         for (int j = 0; j < n_in; ++j) out[PK_LIN + 4 * c + j] = lin_w[c * n_in + j];
+    // nonlinear-branch Jacobian at the origin: W4 diag(1 - t2^2) W2 diag(1 - t1^2) W0
+    std::vector<double> t1(HID), d2(HID), v(HID);
+    for (int k = 0; k < HID; ++k) t1[k] = std::tanh((double)b0[k]);
+    for (int i = 0; i < HID; ++i) {
+        double a = b2[i];
+        for (int k = 0; k < HID; ++k) a += (double)w2[i * HID + k] * t1[k];
+        const double t = std::tanh(a);
+        d2[i] = 1.0 - t * t;
+    }
+    for (int c = 0; c < n_out; ++c) {
+        for (int k = 0; k < HID; ++k) {
+            double a = 0.0;
+            for (int i = 0; i < HID; ++i) a += (double)w4[c * HID + i] * d2[i] * (double)w2[i * HID + k];
+            v[k] = a * (1.0 - t1[k] * t1[k]);
+        }
+        for (int j = 0; j < n_in; ++j) {
+            double a = 0.0;
+            for (int k = 0; k < HID; ++k) a += v[k] * (double)w0[k * n_in + j];
+            out[PK_J0 + 4 * c + j] = (float)a;
+        }
+    }
 }
 
 // Split-fp16 packing: every fragment element W is stored as two halves, Wh = fp16(W) and
@@ -63,7 +84,7 @@ static bool pack_net_h2(const float* const* p, int n_in, int n_out, std::vector<
     auto put = [&](size_t region_floats, int T, int ks, int lane, int j, double w) {
         if (!(std::fabs(w) < 6.0e4)) ok = false;
         const _Float16 h = (_Float16)(float)w;
-        const _Float16 l = (_Float16)(float)((w - (double)(float)h) * 2048.0);
+        const _Float16 l = (_Float16)(float)(w - (double)(float)h);   // unscaled remainder (subnormals kept)
         _Float16* reg = base + 2 * region_floats;
         reg[((((size_t)0 * 4 + T) * 2 + ks) * 64 + lane) * 8 + j] = h;
         reg[((((size_t)1 * 4 + T) * 2 + ks) * 64 + lane) * 8 + j] = l;
