@@ -134,8 +134,10 @@ int nmpc_ctrl_run(nmpc_ctrl* c, int k0, int nsteps, const double* Xs, const doub
 int nmpc_ctrl_stats(nmpc_ctrl* c, long long* stats, void* stream);
 
 /* Optional per-kernel timing of a controller's launches with HIP events recorded on the stream the
- * kernels are launched on.  nmpc_ctrl_profile(c, 1) makes later nmpc_ctrl_run calls bracket every
- * launch with an event pair; nmpc_ctrl_profile_read synchronises the stream, returns per kind
+ * kernels are launched on.  nmpc_ctrl_profile(c, n) with n >= 1 makes later nmpc_ctrl_run calls
+ * bracket every launch of the steps k with k % n == 0 with an event pair (n = 1: every step; an
+ * event pair costs a few microseconds of stream time, so a sparse sample leaves the run's
+ * throughput untouched), n = 0 stops it; nmpc_ctrl_profile_read synchronises the stream, returns per kind
  * (0 embedding, 1 condense+QP solve, 2 plant/observer) the number of launches and their summed
  * duration in ms (arrays of 3), and clears the record. */
 int nmpc_ctrl_profile(nmpc_ctrl* c, int enable);

@@ -244,6 +244,7 @@ struct RunPtrs {
     const double *Xs, *Us, *noise;
     double *x_log, *u_log, *e_log, *y_log, *y_est_log, *plan_log;
     int* lpv_counter;
+    int noise_ld;   // controllers per row of `noise` (the whole batch, also for a slice view)
 };
 
 template <int GS, int MPL, int NX>
@@ -340,6 +341,7 @@ __device__ __forceinline__ void disc_deriv(const double* p, double w, double th,
 }
 
 constexpr int MAX_HIST = 32;
+constexpr int MAX_SLICES = 8;     // independent sub-batches of one controller batch, each on its own stream
 constexpr int PLANT_WAVES = 4;
 
 // one wavefront per controller
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(64 * PLANT_WAVES) void plant_kernel(CtrlDev d, RunP
     disc_deriv(d.plant, w + k3w, th + k3t, u_den, k4w, k4t); k4w *= d.dt; k4t *= d.dt;
     w += (k1w + 2 * k2w + 2 * k3w + k4w) / 6;
     th += (k1t + 2 * k2t + 2 * k3t + k4t) / 6;
-    const double y = th + (rp.noise ? rp.noise[(size_t)k * d.B + b] : 0.0);
+    const double y = th + (rp.noise ? rp.noise[(size_t)k * rp.noise_ld + b] : 0.0);
     const double yn = (y - d.y0) / d.ystd;                          // NMPC_test.py:280
     // observer histories, oldest first (NMPC_test.py:283-289); net input = [u_hist, y_hist]
     double* uh = d.uhist + (size_t)b * d.na;
@@ -440,7 +442,7 @@ template <int NX>
 __global__ void reset_kernel(CtrlDev d, double u0n, double x0a, double x0b, double x0c, double x0d, double pw, double pth) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b == 0) {
-        for (int it = 0; it <= d.maxit; ++it) d.nact[it] = 0;
+        for (int i = 0; i < (d.maxit + 2) * MAX_SLICES; ++i) d.nact[i] = 0;
         *d.qp_fail = 0ull;
     }
     if (b >= d.B) return;
@@ -568,14 +570,27 @@ extern "C" int nmpc_mpc_qp(int nb, int Nc, int nx, const double* list_A, const d
 
 struct ProfRec { hipEvent_t a, b; int kind; };
 
+// A slice is a contiguous range of the batch with its own stream, work lists and counters: the
+// controllers are independent, so slices advance through the step sequence concurrently and the
+// latency-bound QP tail of one slice overlaps the issue-bound embedding pass of another.
+struct CtrlSlice {
+    CtrlDev d;          // view: batch-major pointers advanced to the slice's first controller, B = slice size
+    int b0;
+    hipStream_t stream; // null when the caller's stream is used (single slice)
+    hipEvent_t done;
+};
+
 struct nmpc_ctrl {
     CtrlDev d;
+    std::vector<CtrlSlice> slices;
+    hipEvent_t start = nullptr;
     ModelDev m;
     NodeTable nt;
     MpcGeom g;
     std::vector<void*> allocs;
     int device;
-    bool prof_on = false;
+    int prof_every = 0;               // 0: off; n: event pairs around the launches of steps k % n == 0
+    bool prof_on = false;             // set per step by nmpc_ctrl_run
     std::vector<ProfRec> prof;        // recorded pairs
     std::vector<ProfRec> prof_pool;   // idle pairs
 };
@@ -631,11 +646,46 @@ extern "C" int nmpc_ctrl_create(nmpc_ctrl** out, const nmpc_model* m, const nmpc
     rc |= alloc((void**)&d.xp, sb * 2 * 8); rc |= alloc((void**)&d.uhist, sb * d.na * 8);
     rc |= alloc((void**)&d.yhist, sb * d.nyh * 8); rc |= alloc((void**)&d.eps, sb * 8);
     rc |= alloc((void**)&d.cnt, sb * 4); rc |= alloc((void**)&d.act, sb * (d.maxit + 1) * 4);
-    rc |= alloc((void**)&d.nact, (d.maxit + 2) * 4); rc |= alloc((void**)&d.qp_fail, 8); rc |= alloc((void**)&d.qp_stat, sb * 8);
+    rc |= alloc((void**)&d.nact, (size_t)(d.maxit + 2) * MAX_SLICES * 4); rc |= alloc((void**)&d.qp_fail, 8); rc |= alloc((void**)&d.qp_stat, sb * 8);
     rc |= alloc((void**)&d.xs32, sb * Nc * nx * 4); rc |= alloc((void**)&d.us32, sb * Nc * 4);
     rc |= alloc((void**)&d.xc32, sb * Nc * nx * 4); rc |= alloc((void**)&d.A32, sb * Nc * nx * nx * 4);
     rc |= alloc((void**)&d.B32, sb * Nc * nx * 4); rc |= alloc((void**)&d.C32, sb * Nc * nx * 4);
     if (rc) { nmpc_ctrl_destroy(c); return 1; }
+    // slices: NMPC_CTRL_SLICES (1..8) overrides the default (3 from 1536 controllers, 2 from 1024, else 1;
+    // three slice streams and the caller's stream fill the four hardware queues of a process)
+    int ns = B >= 1536 ? 3 : (B >= 1024 ? 2 : 1);
+    if (const char* e = getenv("NMPC_CTRL_SLICES")) ns = atoi(e);
+    ns = ns < 1 ? 1 : (ns > MAX_SLICES ? MAX_SLICES : ns);
+    if (ns > B) ns = B;
+    const int ntot = d.n_sim + Nc;
+    (void)ntot;
+    for (int i = 0; i < ns; ++i) {
+        CtrlSlice sl;
+        sl.d = d; sl.stream = nullptr; sl.done = nullptr;
+        const int b0 = (int)((long long)B * i / ns), b1 = (int)((long long)B * (i + 1) / ns);
+        const size_t o = (size_t)b0;
+        sl.b0 = b0; sl.d.B = b1 - b0;
+        sl.d.x0n += o * nx; sl.d.xpred += o * Nc * nx; sl.d.uplan += o * Nc; sl.d.ymeas += o; sl.d.xp += o * 2;
+        sl.d.uhist += o * d.na; sl.d.yhist += o * d.nyh; sl.d.eps += o; sl.d.cnt += o;
+        sl.d.act += o * (d.maxit + 1); sl.d.nact += (size_t)(d.maxit + 2) * i; sl.d.qp_stat += o * 2;
+        sl.d.xs32 += o * Nc * nx; sl.d.us32 += o * Nc; sl.d.xc32 += o * Nc * nx;
+        sl.d.A32 += o * Nc * nx * nx; sl.d.B32 += o * Nc * nx; sl.d.C32 += o * Nc * nx;
+        if (ns > 1) {
+            if (hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) {
+                set_error("nmpc_ctrl_create: cannot create slice stream");
+                c->slices.push_back(sl);
+                nmpc_ctrl_destroy(c);
+                return 1;
+            }
+        }
+        c->slices.push_back(sl);
+    }
+    if (ns > 1 && hipEventCreateWithFlags(&c->start, hipEventDisableTiming) != hipSuccess) {
+        set_error("nmpc_ctrl_create: cannot create event");
+        nmpc_ctrl_destroy(c);
+        return 1;
+    }
     *out = c;
     return 0;
 }
@@ -644,6 +694,11 @@ extern "C" void nmpc_ctrl_destroy(nmpc_ctrl* c) {
     if (!c) return;
     for (auto* v : {&c->prof, &c->prof_pool})
         for (ProfRec& r : *v) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (CtrlSlice& sl : c->slices) {
+        if (sl.stream) { (void)hipStreamSynchronize(sl.stream); (void)hipStreamDestroy(sl.stream); }
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
+    if (c->start) (void)hipEventDestroy(c->start);
     for (void* p : c->allocs) (void)hipFree(p);
     delete c;
 }
@@ -667,38 +722,68 @@ extern "C" int nmpc_ctrl_run(nmpc_ctrl* c, int k0, int nsteps, const double* Xs,
     NMPC_REQUIRE(c && Xs && Us, "nmpc_ctrl_run: null argument");
     NMPC_REQUIRE(k0 >= 0 && nsteps >= 0 && k0 + nsteps <= c->d.n_sim, "nmpc_ctrl_run: steps [%d,%d) outside n_sim=%d", k0,
                  k0 + nsteps, c->d.n_sim);
-    hipStream_t s = (hipStream_t)stream;
-    const CtrlDev& d = c->d;
-    RunPtrs rp{Xs, Us, noise, x_log, u_log, e_log, y_log, y_est_log, plan_log, lpv_counter};
+    std::vector<RunPtrs> sl_rp;
+    hipStream_t s0 = (hipStream_t)stream;
+    const int ns = c->d.n_sim, Nc = c->d.Nc, nx = c->d.nx, ntot = ns + Nc;
+    const bool multi = c->slices.size() > 1;
+    if (multi) NMPC_HIP_CHECK(hipEventRecord(c->start, s0));
+    for (CtrlSlice& sl : c->slices) {
+        hipStream_t s = multi ? sl.stream : s0;
+        if (multi) NMPC_HIP_CHECK(hipStreamWaitEvent(s, c->start, 0));
+        const CtrlDev& d = sl.d;
+        const size_t o = (size_t)sl.b0;
+        RunPtrs rp{};
+        rp.Xs = Xs + o * ntot * nx; rp.Us = Us + o * ntot; rp.noise = noise ? noise + o : nullptr; rp.noise_ld = c->d.B;
+        rp.x_log = x_log ? x_log + o * (ns + 1) * nx : nullptr; rp.u_log = u_log ? u_log + o * ns : nullptr;
+        rp.e_log = e_log ? e_log + o * ns : nullptr; rp.y_log = y_log ? y_log + o * (ns + 1) : nullptr;
+        rp.y_est_log = y_est_log ? y_est_log + o * (ns + 1) : nullptr;
+        rp.plan_log = plan_log ? plan_log + o * ns * Nc : nullptr;
+        rp.lpv_counter = lpv_counter ? lpv_counter + o * ns : nullptr;
+        sl_rp.push_back(rp);
+        (void)d; (void)s;
+    }
+    // steps are issued slice by slice within a step so that the streams stay evenly fed
     for (int k = k0; k < k0 + nsteps; ++k) {
-        for (int it = 0; it < d.maxit; ++it) {
-            EmbedArgs a{};
-            a.x = d.xs32; a.u = d.us32; a.xc = d.xc32; a.A = d.A32; a.B = d.B32; a.C = d.C32;
-            a.npts = d.B * d.Nc; a.group = d.Nc;
-            if (it > 0) { a.count_dev = d.nact + it; a.act = d.act + (size_t)it * d.B; }
+        c->prof_on = c->prof_every > 0 && k % c->prof_every == 0;
+        for (size_t i = 0; i < c->slices.size(); ++i) {
+            CtrlSlice& sl = c->slices[i];
+            hipStream_t s = multi ? sl.stream : s0;
+            const CtrlDev& d = sl.d;
+            const RunPtrs& rp = sl_rp[i];
+            for (int it = 0; it < d.maxit; ++it) {
+                EmbedArgs a{};
+                a.x = d.xs32; a.u = d.us32; a.xc = d.xc32; a.A = d.A32; a.B = d.B32; a.C = d.C32;
+                a.npts = d.B * d.Nc; a.group = d.Nc;
+                if (it > 0) { a.count_dev = d.nact + it; a.act = d.act + (size_t)it * d.B; }
+                ProfRec pr;
+                bool on = prof_begin(c, 0, s, pr);
+                if (embed_launch(c->m, a, c->nt, s, true)) return 1;
+                prof_end(c, on, s, pr);
+                on = prof_begin(c, 1, s, pr);
+                if (dispatch_mpc_solve(d, rp, it, k, c->g, s)) return 1;
+                prof_end(c, on, s, pr);
+            }
             ProfRec pr;
-            bool on = prof_begin(c, 0, s, pr);
-            if (embed_launch(c->m, a, c->nt, s, true)) return 1;
-            prof_end(c, on, s, pr);
-            on = prof_begin(c, 1, s, pr);
-            if (dispatch_mpc_solve(d, rp, it, k, c->g, s)) return 1;
+            const bool on = prof_begin(c, 2, s, pr);
+            const int threads = 64 * PLANT_WAVES, grid = (d.B + PLANT_WAVES - 1) / PLANT_WAVES;
+            if (d.nx == 2) hipLaunchKernelGGL((plant_kernel<2>), dim3(grid), dim3(threads), 0, s, d, rp, k);
+            else if (d.nx == 3) hipLaunchKernelGGL((plant_kernel<3>), dim3(grid), dim3(threads), 0, s, d, rp, k);
+            else { set_error("nmpc_ctrl_run: nx=%d unsupported", d.nx); return 1; }
+            NMPC_HIP_CHECK(hipGetLastError());
             prof_end(c, on, s, pr);
         }
-        ProfRec pr;
-        const bool on = prof_begin(c, 2, s, pr);
-        const int threads = 64 * PLANT_WAVES, grid = (d.B + PLANT_WAVES - 1) / PLANT_WAVES;
-        if (d.nx == 2) hipLaunchKernelGGL((plant_kernel<2>), dim3(grid), dim3(threads), 0, s, d, rp, k);
-        else if (d.nx == 3) hipLaunchKernelGGL((plant_kernel<3>), dim3(grid), dim3(threads), 0, s, d, rp, k);
-        else { set_error("nmpc_ctrl_run: nx=%d unsupported", d.nx); return 1; }
-        NMPC_HIP_CHECK(hipGetLastError());
-        prof_end(c, on, s, pr);
     }
+    if (multi)
+        for (CtrlSlice& sl : c->slices) {
+            NMPC_HIP_CHECK(hipEventRecord(sl.done, sl.stream));
+            NMPC_HIP_CHECK(hipStreamWaitEvent(s0, sl.done, 0));
+        }
     return 0;
 }
 
 extern "C" int nmpc_ctrl_profile(nmpc_ctrl* c, int enable) {
     NMPC_REQUIRE(c, "nmpc_ctrl_profile: null argument");
-    c->prof_on = enable != 0;
+    c->prof_every = enable > 0 ? enable : 0;
     return 0;
 }
 

@@ -134,8 +134,9 @@ class Controller:
         check(rc, "nmpc_ctrl_run")
 
     def profile(self, enable=True):
-        """Bracket every kernel launch of later run() calls with HIP events (see profile_read)."""
-        check(lib().nmpc_ctrl_profile(self.handle, 1 if enable else 0), "nmpc_ctrl_profile")
+        """Bracket the kernel launches of later run() calls with HIP events (see profile_read):
+        True / 1 every step, n > 1 the steps k with k % n == 0, False / 0 none."""
+        check(lib().nmpc_ctrl_profile(self.handle, int(enable)), "nmpc_ctrl_profile")
 
     def profile_read(self):
         """{kind: (launches, total_ms)} for kinds embed / solve / plant since the last read."""
