@@ -161,3 +161,21 @@ def test_full_size_properties(enc):
     assert u.min() > -4 - 0.5 and u.max() < 4 + 0.5      # soft input bounds: slack stays small
     y = a[8].cpu().numpy()
     assert np.median(np.abs(y[:, 10:Nsim + 1:5] - refs[:, 9:Nsim:5])) < 0.1
+
+
+def test_slices_do_not_change_results(enc, monkeypatch):
+    """The batch is processed as concurrent slices on separate streams; the slice count must not
+    change a single bit of the logs (noisy measurement: the noise matrix is step-major)."""
+    import nmpc_amd
+    B, Nsim, Nc = 13, 20, 10
+    refs = np.stack([random_level_reference(Nsim + Nc, [10, 15], [-1, 1], np.random.default_rng(50 + b)) for b in range(B)])
+    noise = 0.014 * np.random.default_rng(11).standard_normal((Nsim, B))
+    plant = nmpc_amd.OutputUnbalancedDisc(dt=0.1, sigma_n=[0.014])
+    outs = []
+    for ns in ("1", "3", "5"):
+        monkeypatch.setenv("NMPC_CTRL_SLICES", ns)
+        outs.append(nmpc_amd.output_NMPC_linear(plant, enc, -4, 4, [-1.2], [1.2], np.zeros(2), Q, 1.0, 0.1, 0.05, 20, refs,
+                                                Nc=Nc, Nsim=Nsim, max_iterations=4, noise=noise))
+    for o in outs[1:]:
+        for i in (0, 1, 2, 6, 8, 9):
+            assert torch.equal(outs[0][i], o[i]), i
