@@ -436,7 +436,8 @@ static int embed_launch_t(const EmbedArgs& a, const NodeTable& nt, int grid, siz
     return 0;
 }
 
-// NMPC_EMBED=f32 selects the fp32-MFMA kernel, anything else the split-fp16 kernel
+// NMPC_EMBED=f32 selects the fp32-MFMA kernel, anything else the split-fp16 kernel (when the model's
+// weights suit it: see pack_net_h2)
 static bool embed_use_h2() {
     static int v = -1;
     if (v < 0) {
@@ -459,7 +460,7 @@ int embed_launch(const ModelDev& m, EmbedArgs a, const NodeTable& nodes, hipStre
     const bool do_f = a.x && a.u && a.A && a.B, do_h = a.xc && a.C;
     NMPC_REQUIRE(do_f || do_h, "embed: nothing to compute (need x,u,A,B and/or xc,C)");
     const int tiles = (a.npts + EMBED_TILE - 1) / EMBED_TILE;
-    const bool h2 = embed_use_h2();
+    const bool h2 = embed_use_h2() && m.fpack_h2 && m.hpack_h2;
     a.fpack = h2 ? m.fpack_h2 : m.fpack; a.hpack = h2 ? m.hpack_h2 : m.hpack;
     a.n_ftiles = do_f ? tiles : 0;
     if (a.group < 1) a.group = 1;

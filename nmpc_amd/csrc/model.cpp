@@ -70,7 +70,9 @@ static void pack_net(const float* const* p, int n_in, int n_out, std::vector<flo
 }
 
 // Split-fp16 packing: every fragment element W is stored as two halves, Wh = fp16(W) and
-// Wl' = fp16((W - Wh) 2^11).  Fragment of tile T, k-step ks: lane l (row 16T + (l&15), quarter
+// Wl = fp16(W - Wh) (unscaled; subnormal for |W| < 1/8, absolute resolution 2^-24).  Returns false
+// when the fragments do not suit that format: an entry beyond the fp16 range, or a matrix whose
+// largest entry is below 2^-6 (the absolute resolution would cost relative accuracy).  Fragment of tile T, k-step ks: lane l (row 16T + (l&15), quarter
 // hq = l>>4) holds 8 halves j = 0..7 for the hidden unit 16 (2 ks + (j>>2)) + 4 hq + (j&3), i.e.
 // unit s = 8 ks + j in the kernel's numbering.  Region layout: [plane][T][ks][lane][8 halves].
 static bool pack_net_h2(const float* const* p, int n_in, int n_out, std::vector<float>& out) {
@@ -81,8 +83,11 @@ static bool pack_net_h2(const float* const* p, int n_in, int n_out, std::vector<
     const double c2 = 2.0 * 1.4426950408889634074;
     _Float16* base = reinterpret_cast<_Float16*>(out.data());
     bool ok = true;
+    double wmax[5] = {0, 0, 0, 0, 0};              // forward matrix, reverse matrices c = 0..3
     auto put = [&](size_t region_floats, int T, int ks, int lane, int j, double w) {
         if (!(std::fabs(w) < 6.0e4)) ok = false;
+        double& mx = wmax[region_floats == (size_t)PK_WF ? 0 : 1 + (region_floats - PK_WR) / 4096];
+        mx = std::fabs(w) > mx ? std::fabs(w) : mx;
         const _Float16 h = (_Float16)(float)w;
         const _Float16 l = (_Float16)(float)(w - (double)(float)h);   // unscaled remainder (subnormals kept)
         _Float16* reg = base + 2 * region_floats;
@@ -99,6 +104,8 @@ static bool pack_net_h2(const float* const* p, int n_in, int n_out, std::vector<
                     for (int c = 0; c < n_out; ++c)
                         put(PK_WR + 4096 * c, T, ks, lane, j, (double)w2[k * HID + 16 * T + r] * 4.0 * (double)w4[c * HID + k]);
                 }
+    for (int i = 0; i <= n_out; ++i)
+        if (wmax[i] < 1.0 / 64.0) ok = false;
     return ok;
 }
 
@@ -146,12 +153,14 @@ extern "C" int nmpc_model_create(nmpc_model** out, int nx, int nu, int ny, int h
     pack_net(hn, nx, ny, buf);
     NMPC_HIP_CHECK(hipMalloc(&m->d.hpack, PACK_FLOATS * sizeof(float)));
     NMPC_HIP_CHECK(hipMemcpy(m->d.hpack, buf.data(), PACK_FLOATS * sizeof(float), hipMemcpyHostToDevice));
-    NMPC_REQUIRE(pack_net_h2(fn, nx + nu, nx, buf), "nmpc_model_create: f-net weights exceed the fp16 range");
-    NMPC_HIP_CHECK(hipMalloc(&m->d.fpack_h2, PACK_FLOATS * sizeof(float)));
-    NMPC_HIP_CHECK(hipMemcpy(m->d.fpack_h2, buf.data(), PACK_FLOATS * sizeof(float), hipMemcpyHostToDevice));
-    NMPC_REQUIRE(pack_net_h2(hn, nx, ny, buf), "nmpc_model_create: h-net weights exceed the fp16 range");
-    NMPC_HIP_CHECK(hipMalloc(&m->d.hpack_h2, PACK_FLOATS * sizeof(float)));
-    NMPC_HIP_CHECK(hipMemcpy(m->d.hpack_h2, buf.data(), PACK_FLOATS * sizeof(float), hipMemcpyHostToDevice));
+    // nets whose weights do not suit the split-fp16 fragments run on the fp32-MFMA kernel (both null)
+    std::vector<float> buf2;
+    if (pack_net_h2(fn, nx + nu, nx, buf) && pack_net_h2(hn, nx, ny, buf2)) {
+        NMPC_HIP_CHECK(hipMalloc(&m->d.fpack_h2, PACK_FLOATS * sizeof(float)));
+        NMPC_HIP_CHECK(hipMemcpy(m->d.fpack_h2, buf.data(), PACK_FLOATS * sizeof(float), hipMemcpyHostToDevice));
+        NMPC_HIP_CHECK(hipMalloc(&m->d.hpack_h2, PACK_FLOATS * sizeof(float)));
+        NMPC_HIP_CHECK(hipMemcpy(m->d.hpack_h2, buf2.data(), PACK_FLOATS * sizeof(float), hipMemcpyHostToDevice));
+    }
     eval_net_at_zero(fn, nx + nu, nx, hidden, m->d.f0);
     eval_net_at_zero(hn, nx, ny, hidden, m->d.h0);
     auto upload_plain = [&](const float* const* p, int n_in, int n_out, float** dst) -> int {
