@@ -46,93 +46,162 @@ __host__ __device__ inline int mpc_lds_doubles(int Nc, int nx) {
 }
 
 // Fills qp.Lm (Hessian, lower triangle), qp.xt (linear term), qp.Nt / qp.hv (constraint rows) from
-// Ak, Bk, Ck, x0, Xs, Us.  Leaves xi and Gam for mpc_predict.
-template <int GS, int NX>
-__device__ void mpc_assemble(const MpcConst& c, MpcLds& L, double ymeas, int gl) {
-    const int Nc = c.Nc, n = Nc + 1, mt = 4 * Nc + 2;
-    for (int e = gl; e < NX * NX; e += GS) {
-        const double id = (e / NX == e % NX) ? 1.0 : 0.0;
-        L.Pk[e] = id; L.Sk[e] = id;
+// Ak, Bk, Ck, x0, Xs, Us.  Leaves xi and Gam for mpc_predict.  Uses Sk[0 .. Nc*NX) as scratch for
+// Q (xi_i - Xs_i).
+//
+// Condensing runs as independent recurrences, one per lane and entirely in registers (the only
+// LDS traffic on the critical path is the broadcast read of A_d):
+//   lane j < Nc : column j of Gamma,  Gamma_{j,j} = B_j,  Gamma_{j+d,j} = A_d Gamma_{j+d-1,j}
+//                 (P_d B_j with the prefix products P_d = A_d P_{d-1}, P_0 = I of mpcUtil.py:98-117)
+//   lane Nc     : free response xi_i = P_i A_0 x0 + (sum_{j<=i} P_j) f0   (mpcUtil.py:84-96,119-134)
+// The Hessian and the output-constraint rows are then one work item per lower-triangular pair
+// (a, b): G_ab = 2 sum_i Gamma_{i,a}' Q Gamma_{i,b} (+ 2R on the diagonal), the diagonal item also
+// carries F_a, and the same item writes the two y-rows' coefficient C_a Gamma_{a,b}.
+template <int GS, int NX, int NC = 0>
+__device__ __forceinline__ void mpc_assemble(const MpcConst& c, MpcLds& L, double ymeas, int gl, unsigned long long* st = nullptr) {
+    const int Nc = NC ? NC : c.Nc, n = Nc + 1, mt = 4 * Nc + 2;   // NC > 0: horizon known at compile time
+    double* Lm = L.qp.Lm; double* Nt = L.qp.Nt; double* qd = L.Sk;
+    if (st && gl == 0) st[8] = __builtin_amdgcn_s_memtime();
+    for (int e = gl; e < n * n; e += GS) Lm[e] = e == n * n - 1 ? c.rho : 0.0;
+    for (int e = gl; e < n * mt; e += GS) Nt[e] = e >= Nc * mt ? -1.0 : 0.0;      // slack column: -1 on every row
+    for (int e = gl; e < Nc * Nc * NX; e += GS) L.Gam[e] = 0.0;
+    if (gl == 0) L.qp.xt[Nc] = 0.0;
+    g_sync();
+    if (st && gl == 0) st[9] = __builtin_amdgcn_s_memtime();
+    // A_d is the same for every lane: with one controller per wave it is kept one entry per lane in
+    // registers and broadcast through v_readlane, otherwise it is read from LDS.
+    const bool a_in_regs = GS == 64 && Nc * NX * NX <= 128;
+    double areg[2] = {0.0, 0.0};
+    if (a_in_regs) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (gl + 64 * h < Nc * NX * NX) areg[h] = L.Ak[gl + 64 * h];
+    }
+    for (int j0 = 0; j0 < n; j0 += GS) {           // one trip when Nc + 1 <= GS
+        const int j = j0 + gl;
+        const bool col = j < Nc, fr = j == Nc;
+        double v[NX], pf[NX], sf[NX];
+#pragma unroll
+        for (int r = 0; r < NX; ++r) {
+            v[r] = col ? L.Bk[j * NX + r] : 0.0;
+            pf[r] = c.f0[r]; sf[r] = c.f0[r];
+        }
+        if (fr) {
+#pragma unroll
+            for (int r = 0; r < NX; ++r) {
+                double a = 0.0;
+#pragma unroll
+                for (int l = 0; l < NX; ++l) a = fma(L.Ak[r * NX + l], L.x0[l], a);
+                v[r] = a;
+            }
+        }
+        auto emit = [&](int d) {
+            if (col && j + d < Nc) {
+#pragma unroll
+                for (int r = 0; r < NX; ++r) L.Gam[((j + d) * Nc + j) * NX + r] = v[r];
+            }
+            if (fr) {
+#pragma unroll
+                for (int r = 0; r < NX; ++r) L.xi[d * NX + r] = v[r] + sf[r];
+            }
+        };
+        emit(0);
+        auto step = [&](const double* A, int d) {
+            double nv[NX], np[NX];
+#pragma unroll
+            for (int r = 0; r < NX; ++r) {
+                double a = 0.0, b2 = 0.0;
+#pragma unroll
+                for (int l = 0; l < NX; ++l) { a = fma(A[r * NX + l], v[l], a); b2 = fma(A[r * NX + l], pf[l], b2); }
+                nv[r] = a; np[r] = b2;
+            }
+#pragma unroll
+            for (int r = 0; r < NX; ++r) { v[r] = nv[r]; pf[r] = np[r]; sf[r] += np[r]; }
+            emit(d);
+        };
+        if (a_in_regs) {
+#pragma unroll
+            for (int d = 1; d < (NC ? NC : 1); ++d) {          // fully unrolled when the horizon is a constant
+                double A[NX * NX];
+#pragma unroll
+                for (int e = 0; e < NX * NX; ++e) {
+                    const int idx = d * NX * NX + e;
+                    A[e] = readlane_d(areg[idx >> 6], idx & 63);
+                }
+                step(A, d);
+            }
+            for (int d = NC ? NC : 1; d < Nc; ++d) {
+                double A[NX * NX];
+#pragma unroll
+                for (int e = 0; e < NX * NX; ++e) {
+                    const int idx = d * NX * NX + e;
+                    const double lo_ = readlane_d(areg[0], idx & 63), hi_ = readlane_d(areg[1], idx & 63);
+                    A[e] = idx < 64 ? lo_ : hi_;
+                }
+                step(A, d);
+            }
+        } else {
+            for (int d = 1; d < Nc; ++d) {
+                double A[NX * NX];
+#pragma unroll
+                for (int e = 0; e < NX * NX; ++e) A[e] = L.Ak[d * NX * NX + e];
+                step(A, d);
+            }
+        }
     }
     g_sync();
-    for (int m = 1; m < Nc; ++m) {
-        for (int e = gl; e < NX * NX; e += GS) {
-            const int r = e / NX, cc = e % NX;
-            double a = 0.0;
-#pragma unroll
-            for (int l = 0; l < NX; ++l) a += L.Ak[(m * NX + r) * NX + l] * L.Pk[((m - 1) * NX + l) * NX + cc];
-            L.Pk[m * NX * NX + e] = a;
-            L.Sk[m * NX * NX + e] = L.Sk[(m - 1) * NX * NX + e] + a;
-        }
-        g_sync();
-    }
-    double a0x[NX];
-#pragma unroll
-    for (int l = 0; l < NX; ++l) {
+    for (int e = gl; e < Nc * NX; e += GS) {       // qd_i = Q (xi_i - Xs_i)
+        const int i = e / NX, r = e % NX;
         double a = 0.0;
 #pragma unroll
-        for (int cc = 0; cc < NX; ++cc) a += L.Ak[l * NX + cc] * L.x0[cc];
-        a0x[l] = a;
-    }
-    for (int e = gl; e < Nc * NX; e += GS) {
-        double a = 0.0;
-#pragma unroll
-        for (int l = 0; l < NX; ++l) a += L.Pk[e * NX + l] * a0x[l] + L.Sk[e * NX + l] * c.f0[l];
-        L.xi[e] = a;
-    }
-    for (int e = gl; e < Nc * Nc * NX; e += GS) {
-        const int i = e / (Nc * NX), j = (e / NX) % Nc, r = e % NX;
-        double a = 0.0;
-        if (j <= i) {
-#pragma unroll
-            for (int l = 0; l < NX; ++l) a += L.Pk[((i - j) * NX + r) * NX + l] * L.Bk[j * NX + l];
-        }
-        L.Gam[e] = a;
+        for (int l = 0; l < NX; ++l) a = fma(c.Q[r * NX + l], L.xi[i * NX + l] - L.Xs[i * NX + l], a);
+        qd[e] = a;
     }
     g_sync();
-    double* Lm = L.qp.Lm; double* Nt = L.qp.Nt;
-    for (int e = gl; e < n * n; e += GS) {
-        const int a_ = e / n, b_ = e % n;
-        double v = 0.0;
-        if (a_ < Nc && b_ <= a_) {
-            for (int i = a_; i < Nc; ++i) {
+    if (st && gl == 0) st[10] = __builtin_amdgcn_s_memtime();
+    constexpr int UNR_I = NC ? NC : 5;
+    const int items = Nc * (Nc + 1) / 2;
+    for (int t0 = 0; t0 < items; t0 += GS) {
+        const int t = t0 + gl;
+        const bool on = t < items;
+        int a_ = (int)((__builtin_sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        while ((a_ + 1) * (a_ + 2) / 2 <= t) ++a_;
+        while (a_ * (a_ + 1) / 2 > t) --a_;
+        if (!on) a_ = 0;
+        const int b_ = on ? t - a_ * (a_ + 1) / 2 : 0;
+        double g = 0.0, f = 0.0;
+#pragma unroll UNR_I
+        for (int i = 0; i < Nc; ++i) {             // Gamma_{i,a} = 0 for i < a: uniform trip count
+            double ga[NX], gb[NX];
 #pragma unroll
-                for (int r = 0; r < NX; ++r) {
-                    double qg = 0.0;
+            for (int r = 0; r < NX; ++r) { ga[r] = L.Gam[(i * Nc + a_) * NX + r]; gb[r] = L.Gam[(i * Nc + b_) * NX + r]; }
 #pragma unroll
-                    for (int l = 0; l < NX; ++l) qg += c.Q[r * NX + l] * L.Gam[(i * Nc + b_) * NX + l];
-                    v += L.Gam[(i * Nc + a_) * NX + r] * qg;
-                }
+            for (int r = 0; r < NX; ++r) {
+                double qg = 0.0;
+#pragma unroll
+                for (int l = 0; l < NX; ++l) qg = fma(c.Q[r * NX + l], gb[l], qg);
+                g = fma(ga[r], qg, g);
+                f = fma(ga[r], qd[i * NX + r], f);
             }
-            v = 2.0 * (v + (a_ == b_ ? c.R : 0.0));
-        } else if (a_ == Nc && b_ == Nc) {
-            v = c.rho;
         }
-        Lm[e] = v;
-    }
-    for (int a_ = gl; a_ < n; a_ += GS) {
-        double v = 0.0;
-        if (a_ < Nc) {
-            for (int i = a_; i < Nc; ++i) {
+        if (on) {
+            Lm[a_ * n + b_] = 2.0 * (g + (a_ == b_ ? c.R : 0.0));
+            if (a_ == b_) L.qp.xt[a_] = 2.0 * (f - c.R * L.Us[a_]);
+            // y_{a+1} = C_a x_{a+1} + h0:  rows -/+ of block a+1 (the last block has its own two rows)
+            double cg = 0.0;
 #pragma unroll
-                for (int r = 0; r < NX; ++r) {
-                    double qd = 0.0;
-#pragma unroll
-                    for (int l = 0; l < NX; ++l) qd += c.Q[r * NX + l] * (L.xi[i * NX + l] - L.Xs[i * NX + l]);
-                    v += L.Gam[(i * Nc + a_) * NX + r] * qd;
-                }
-            }
-            v = 2.0 * (v - c.R * L.Us[a_]);
+            for (int r = 0; r < NX; ++r) cg = fma(L.Ck[a_ * NX + r], L.Gam[(a_ * Nc + b_) * NX + r], cg);
+            const int rowm = a_ + 1 < Nc ? 4 * (a_ + 1) + 2 : 4 * Nc;
+            Nt[b_ * mt + rowm] = -cg;
+            Nt[b_ * mt + rowm + 1] = cg;
         }
-        L.qp.xt[a_] = v;
     }
-    // rows 4i+{0,1}: -/+ u_i;  4i+{2,3}: -/+ y_i (y_0 measured, y_i = C_{i-1} x_i + h0);  last two: -/+ y_Nc
+    if (st && gl == 0) st[11] = __builtin_amdgcn_s_memtime();
+    // rows 4i+{0,1}: -/+ u_i;  4i+{2,3}: -/+ y_i (y_0 measured);  last two: -/+ y_Nc
     for (int row = gl; row < mt; row += GS) {
         const int blk = row < 4 * Nc ? row / 4 : Nc;
         const int kind = row < 4 * Nc ? row % 4 : 2 + (row - 4 * Nc);
         const double sg = (kind & 1) ? 1.0 : -1.0;
-        for (int k = 0; k < Nc; ++k) Nt[k * mt + row] = 0.0;
-        Nt[Nc * mt + row] = -1.0;
         double hval;
         if (kind < 2) {
             Nt[blk * mt + row] = sg;
@@ -140,16 +209,9 @@ __device__ void mpc_assemble(const MpcConst& c, MpcLds& L, double ymeas, int gl)
         } else {
             double yv = ymeas;
             if (blk > 0) {
-                const int i = blk - 1;
-                for (int k = 0; k <= i; ++k) {
-                    double a = 0.0;
-#pragma unroll
-                    for (int r = 0; r < NX; ++r) a += L.Ck[i * NX + r] * L.Gam[(i * Nc + k) * NX + r];
-                    Nt[k * mt + row] = sg * a;
-                }
                 yv = c.h0;
 #pragma unroll
-                for (int r = 0; r < NX; ++r) yv += L.Ck[i * NX + r] * L.xi[i * NX + r];
+                for (int r = 0; r < NX; ++r) yv = fma(L.Ck[(blk - 1) * NX + r], L.xi[(blk - 1) * NX + r], yv);
             }
             hval = (kind == 2 ? -c.ymin : c.ymax) - sg * yv;
         }
@@ -159,9 +221,9 @@ __device__ void mpc_assemble(const MpcConst& c, MpcLds& L, double ymeas, int gl)
 }
 
 // x_pred = Phi x0 + Gamma u + F0 with u = qp.xt[0..Nc); writes into xi (in place)
-template <int GS, int NX>
-__device__ void mpc_predict(const MpcConst& c, MpcLds& L, int gl) {
-    const int Nc = c.Nc;
+template <int GS, int NX, int NC = 0>
+__device__ __forceinline__ void mpc_predict(const MpcConst& c, MpcLds& L, int gl) {
+    const int Nc = NC ? NC : c.Nc;
     g_sync();
     for (int e = gl; e < Nc * NX; e += GS) {
         const int i = e / NX, r = e % NX;
@@ -178,20 +240,20 @@ struct MpcQpArgs {
     const double *lA, *lB, *lC, *x0, *ymeas, *Xs, *Us;
     double *Ge, *Fe, *Le, *hv, *u, *eps, *xpred;
     int* status;
-    unsigned long long* stamps;   // optional diagnostics: 8 clock values per problem
+    unsigned long long* stamps;   // optional diagnostics: 12 clock values per problem
     MpcConst c;
 };
 
-template <int GS, int MPL, int NX>
+template <int GS, int MPL, int NX, int NC = 0>
 __global__ void mpc_qp_kernel(MpcQpArgs a) {
     extern __shared__ __align__(16) double mpc_lds[];
     const int gpb = blockDim.x / GS, g = threadIdx.x / GS, gl = threadIdx.x % GS;
     const int prob = blockIdx.x * gpb + g;
     if (prob >= a.nb) return;
-    const int Nc = a.c.Nc, n = Nc + 1, mt = 4 * Nc + 2;
+    const int Nc = NC ? NC : a.c.Nc, n = Nc + 1, mt = 4 * Nc + 2;
     MpcLds L;
     L.carve(mpc_lds + (size_t)g * mpc_lds_doubles(Nc, NX), Nc, NX);
-    unsigned long long* st = a.stamps ? a.stamps + (size_t)prob * 8 : nullptr;
+    unsigned long long* st = a.stamps ? a.stamps + (size_t)prob * 12 : nullptr;
     if (st && gl == 0) st[0] = __builtin_amdgcn_s_memtime();
     for (int e = gl; e < Nc * NX * NX; e += GS) L.Ak[e] = a.lA[(size_t)prob * Nc * NX * NX + e];
     for (int e = gl; e < Nc * NX; e += GS) {
@@ -202,17 +264,19 @@ __global__ void mpc_qp_kernel(MpcQpArgs a) {
     for (int e = gl; e < Nc; e += GS) L.Us[e] = a.Us[(size_t)prob * Nc + e];
     for (int e = gl; e < NX; e += GS) L.x0[e] = a.x0[(size_t)prob * NX + e];
     g_sync();
-    mpc_assemble<GS, NX>(a.c, L, a.ymeas[prob], gl);
+    mpc_assemble<GS, NX, NC>(a.c, L, a.ymeas[prob], gl, st);
     if (st && gl == 0) st[1] = __builtin_amdgcn_s_memtime();
     if (a.Ge) for (int e = gl; e < n * n; e += GS) a.Ge[(size_t)prob * n * n + e] = L.qp.Lm[e];
     if (a.Fe) for (int e = gl; e < n; e += GS) a.Fe[(size_t)prob * n + e] = L.qp.xt[e];
     if (a.Le) for (int e = gl; e < mt * n; e += GS) a.Le[(size_t)prob * mt * n + e] = L.qp.Nt[(e % n) * mt + e / n];
     if (a.hv) for (int e = gl; e < mt; e += GS) a.hv[(size_t)prob * mt + e] = L.qp.hv[e];
     if (!a.u && !a.xpred && !a.eps) return;
-    const int stt = (GS == 64 && n <= 16) ? gi_solve<GS, MPL, (GS == 64 ? 16 : 0)>(n, mt, 0, L.qp, nullptr, nullptr, st ? st + 2 : nullptr)
-                                          : gi_solve<GS, MPL>(n, mt, 0, L.qp, nullptr, nullptr, st ? st + 2 : nullptr);
+    int stt;
+    if constexpr (GS == 64 && NC > 0 && NC + 1 <= 16) stt = gi_solve<GS, MPL, NC + 1>(n, mt, 0, L.qp, nullptr, nullptr, st ? st + 2 : nullptr);
+    else stt = (GS == 64 && n <= 16) ? gi_solve<GS, MPL, (GS == 64 ? 16 : 0)>(n, mt, 0, L.qp, nullptr, nullptr, st ? st + 2 : nullptr)
+                                     : gi_solve<GS, MPL>(n, mt, 0, L.qp, nullptr, nullptr, st ? st + 2 : nullptr);
     const double epsv = L.qp.xt[Nc];
-    mpc_predict<GS, NX>(a.c, L, gl);
+    mpc_predict<GS, NX, NC>(a.c, L, gl);
     if (st && gl == 0) st[7] = __builtin_amdgcn_s_memtime();
     if (a.u) for (int e = gl; e < Nc; e += GS) a.u[(size_t)prob * Nc + e] = L.qp.xt[e];
     if (a.xpred) for (int e = gl; e < Nc * NX; e += GS) a.xpred[(size_t)prob * Nc * NX + e] = L.xi[e];
@@ -247,7 +311,7 @@ struct RunPtrs {
     int noise_ld;   // controllers per row of `noise` (the whole batch, also for a slice view)
 };
 
-template <int GS, int MPL, int NX>
+template <int GS, int MPL, int NX, int NC = 0>
 __global__ void mpc_solve_kernel(CtrlDev d, RunPtrs rp, int it, int k) {
     extern __shared__ __align__(16) double mpc_lds[];
     const int gpb = blockDim.x / GS, g = threadIdx.x / GS, gl = threadIdx.x % GS;
@@ -255,7 +319,7 @@ __global__ void mpc_solve_kernel(CtrlDev d, RunPtrs rp, int it, int k) {
     const int count = it == 0 ? d.B : min(d.nact[it], d.B);
     if (gid >= count) return;
     const int b = it == 0 ? gid : d.act[(size_t)it * d.B + gid];
-    const int Nc = d.Nc, n = Nc + 1, mt = 4 * Nc + 2, ntot = d.n_sim + Nc;
+    const int Nc = NC ? NC : d.Nc, n = Nc + 1, mt = 4 * Nc + 2, ntot = d.n_sim + Nc;
     MpcLds L;
     L.carve(mpc_lds + (size_t)g * mpc_lds_doubles(Nc, NX), Nc, NX);
     for (int e = gl; e < Nc * NX * NX; e += GS) L.Ak[e] = (double)d.A32[(size_t)b * Nc * NX * NX + e];
@@ -271,12 +335,14 @@ __global__ void mpc_solve_kernel(CtrlDev d, RunPtrs rp, int it, int k) {
     }
     for (int e = gl; e < NX; e += GS) L.x0[e] = d.x0n[(size_t)b * NX + e];
     g_sync();
-    mpc_assemble<GS, NX>(d.c, L, d.ymeas[b], gl);
+    mpc_assemble<GS, NX, NC>(d.c, L, d.ymeas[b], gl);
     int qp_it = 0;
-    const int st = (GS == 64 && n <= 16) ? gi_solve<GS, MPL, (GS == 64 ? 16 : 0)>(n, mt, 0, L.qp, nullptr, &qp_it)
-                                         : gi_solve<GS, MPL>(n, mt, 0, L.qp, nullptr, &qp_it);
+    int st;
+    if constexpr (GS == 64 && NC > 0 && NC + 1 <= 16) st = gi_solve<GS, MPL, NC + 1>(n, mt, 0, L.qp, nullptr, &qp_it);
+    else st = (GS == 64 && n <= 16) ? gi_solve<GS, MPL, (GS == 64 ? 16 : 0)>(n, mt, 0, L.qp, nullptr, &qp_it)
+                                    : gi_solve<GS, MPL>(n, mt, 0, L.qp, nullptr, &qp_it);
     const double epsv = L.qp.xt[Nc];
-    mpc_predict<GS, NX>(d.c, L, gl);
+    mpc_predict<GS, NX, NC>(d.c, L, gl);
     double du = 0.0;
     for (int e = gl; e < Nc; e += GS) {
         const double un = L.qp.xt[e], dd = un - L.uold[e];
@@ -498,20 +564,21 @@ static int set_lds_attr(K kernel) {
     return 0;
 }
 
-template <int GS, int MPL, int NX>
+// NC: horizon as a compile-time constant (0 = read it from the arguments)
+template <int GS, int MPL, int NX, int NC = 0>
 static int launch_mpc_qp(const MpcQpArgs& a, const MpcGeom& g, hipStream_t s) {
     static bool once = false;
-    if (!once) { if (set_lds_attr(mpc_qp_kernel<GS, MPL, NX>)) return 1; once = true; }
-    hipLaunchKernelGGL((mpc_qp_kernel<GS, MPL, NX>), dim3((a.nb + g.gpb - 1) / g.gpb), dim3(g.gpb * GS), g.lds, s, a);
+    if (!once) { if (set_lds_attr(mpc_qp_kernel<GS, MPL, NX, NC>)) return 1; once = true; }
+    hipLaunchKernelGGL((mpc_qp_kernel<GS, MPL, NX, NC>), dim3((a.nb + g.gpb - 1) / g.gpb), dim3(g.gpb * GS), g.lds, s, a);
     NMPC_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
-template <int GS, int MPL, int NX>
+template <int GS, int MPL, int NX, int NC = 0>
 static int launch_mpc_solve(const CtrlDev& d, const RunPtrs& rp, int it, int k, const MpcGeom& g, hipStream_t s) {
     static bool once = false;
-    if (!once) { if (set_lds_attr(mpc_solve_kernel<GS, MPL, NX>)) return 1; once = true; }
-    hipLaunchKernelGGL((mpc_solve_kernel<GS, MPL, NX>), dim3((d.B + g.gpb - 1) / g.gpb), dim3(g.gpb * GS), g.lds, s, d, rp, it, k);
+    if (!once) { if (set_lds_attr(mpc_solve_kernel<GS, MPL, NX, NC>)) return 1; once = true; }
+    hipLaunchKernelGGL((mpc_solve_kernel<GS, MPL, NX, NC>), dim3((d.B + g.gpb - 1) / g.gpb), dim3(g.gpb * GS), g.lds, s, d, rp, it, k);
     NMPC_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -526,7 +593,10 @@ static int launch_mpc_solve(const CtrlDev& d, const RunPtrs& rp, int it, int k, 
     if (g.GS == 64 && g.mpl <= 2) return FN<64, 2, NX_>(__VA_ARGS__);             \
     if (g.GS == 64 && g.mpl <= 4) return FN<64, 4, NX_>(__VA_ARGS__);
 
+// The horizon of the reference's canonical configuration (Nc = 10, nx = 2: NMPC_test.py:326-344) has
+// kernels of its own with every loop bound a constant.
 static int dispatch_mpc_qp(const MpcQpArgs& a, const MpcGeom& g, hipStream_t s) {
+    if (a.nx == 2 && a.c.Nc == 10 && g.GS == 64 && g.mpl <= 1) return launch_mpc_qp<64, 1, 2, 10>(a, g, s);
     if (a.nx == 2) { NMPC_GEOM_SWITCH(launch_mpc_qp, 2, g, a, g, s) }
     if (a.nx == 3) { NMPC_GEOM_SWITCH(launch_mpc_qp, 3, g, a, g, s) }
     set_error("nmpc_mpc_qp: no kernel for nx=%d GS=%d rows/lane=%d", a.nx, g.GS, g.mpl);
@@ -534,6 +604,7 @@ static int dispatch_mpc_qp(const MpcQpArgs& a, const MpcGeom& g, hipStream_t s) 
 }
 
 static int dispatch_mpc_solve(const CtrlDev& d, const RunPtrs& rp, int it, int k, const MpcGeom& g, hipStream_t s) {
+    if (d.nx == 2 && d.Nc == 10 && g.GS == 64 && g.mpl <= 1) return launch_mpc_solve<64, 1, 2, 10>(d, rp, it, k, g, s);
     if (d.nx == 2) { NMPC_GEOM_SWITCH(launch_mpc_solve, 2, g, d, rp, it, k, g, s) }
     if (d.nx == 3) { NMPC_GEOM_SWITCH(launch_mpc_solve, 3, g, d, rp, it, k, g, s) }
     set_error("nmpc_ctrl_run: no kernel for nx=%d GS=%d rows/lane=%d", d.nx, g.GS, g.mpl);

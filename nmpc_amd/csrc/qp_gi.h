@@ -23,18 +23,67 @@ namespace nmpc {
 
 constexpr double QP_INF = 1e300;
 
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)b, lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// Whole-wave (GS = 64) reductions stay off the LDS crossbar: butterflies inside each row of 16
+// lanes on the DPP network (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), the four row
+// results through v_readlane.  Every lane ends with the same value; the order of operations is fixed.
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)b, CTRL, 0xf, 0xf, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+__device__ __forceinline__ double wave_sum(double v) {
+    v += dpp_d<DPP_XOR1>(v); v += dpp_d<DPP_XOR2>(v); v += dpp_d<DPP_HALF_MIRROR>(v); v += dpp_d<DPP_MIRROR>(v);
+    return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
+}
+__device__ __forceinline__ double wave_min(double v) {
+    v = fmin(v, dpp_d<DPP_XOR1>(v)); v = fmin(v, dpp_d<DPP_XOR2>(v));
+    v = fmin(v, dpp_d<DPP_HALF_MIRROR>(v)); v = fmin(v, dpp_d<DPP_MIRROR>(v));
+    return fmin(fmin(readlane_d(v, 0), readlane_d(v, 16)), fmin(readlane_d(v, 32), readlane_d(v, 48)));
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+    v = min(v, __builtin_amdgcn_mov_dpp(v, DPP_XOR1, 0xf, 0xf, true)); v = min(v, __builtin_amdgcn_mov_dpp(v, DPP_XOR2, 0xf, 0xf, true));
+    v = min(v, __builtin_amdgcn_mov_dpp(v, DPP_HALF_MIRROR, 0xf, 0xf, true)); v = min(v, __builtin_amdgcn_mov_dpp(v, DPP_MIRROR, 0xf, 0xf, true));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+// value of group lane src_gl, which must be the same in every lane of the group
 template <int GS>
 __device__ __forceinline__ double g_bcast(double v, int src_gl) {
+    if constexpr (GS == 64) return readlane_d(v, src_gl);
     const int lane = threadIdx.x & 63;
     return __shfl(v, (lane & ~(GS - 1)) + src_gl, 64);
 }
 template <int GS>
 __device__ __forceinline__ int g_bcast_i(int v, int src_gl) {
+    if constexpr (GS == 64) return __builtin_amdgcn_readlane(v, src_gl);
     const int lane = threadIdx.x & 63;
     return __shfl(v, (lane & ~(GS - 1)) + src_gl, 64);
 }
+// value of the next lane of the group (cyclic)
+template <int GS>
+__device__ __forceinline__ double g_next(double v) {
+    const int lane = threadIdx.x & 63;
+    return __shfl(v, (lane & ~(GS - 1)) + ((lane + 1) & (GS - 1)), 64);
+}
+template <int GS>
+__device__ __forceinline__ int g_next_i(int v) {
+    const int lane = threadIdx.x & 63;
+    return __shfl(v, (lane & ~(GS - 1)) + ((lane + 1) & (GS - 1)), 64);
+}
 template <int GS>
 __device__ __forceinline__ double g_sum(double v) {
+    if constexpr (GS == 64) return wave_sum(v);
 #pragma unroll
     for (int m = GS / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
     return v;
@@ -42,6 +91,12 @@ __device__ __forceinline__ double g_sum(double v) {
 // minimum and its index (ties -> smaller index), result identical in every lane of the group
 template <int GS>
 __device__ __forceinline__ void g_argmin(double& v, int& idx) {
+    if constexpr (GS == 64) {
+        const double m = wave_min(v);
+        idx = wave_min_i(v == m ? idx : 0x7fffffff);
+        v = m;
+        return;
+    }
 #pragma unroll
     for (int m = GS / 2; m >= 1; m >>= 1) {
         const double ov = __shfl_xor(v, m, 64);
@@ -78,13 +133,6 @@ __device__ __forceinline__ bool g_chol(double* M, int nn, int ld, double* invd, 
         g_sync();
     }
     return true;
-}
-
-__device__ __forceinline__ double readlane_d(double v, int lane) {
-    const long long b = __builtin_bit_cast(long long, v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)b, lane);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), lane);
-    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
 // 1/sqrt(d) to full fp64 accuracy: hardware estimate + two Newton steps
@@ -183,7 +231,7 @@ struct QPWork {
 // after the active-set loop, at exit] written by the group's first lane.
 // NMAX > 0 (only with GS = 64): n <= NMAX, Cholesky and transform run in registers.
 template <int GS, int MPL, int NMAX = 0>
-__device__ int gi_solve(int n, int mt, int meq, QPWork& w, double* lam, int* iters_out,
+__device__ __forceinline__ int gi_solve(int n, int mt, int meq, QPWork& w, double* lam, int* iters_out,
                         unsigned long long* stamp = nullptr) {
     const int gl = (threadIdx.x & 63) & (GS - 1);
     double *Lm = w.Lm, *Nt = w.Nt, *hv = w.hv, *xt = w.xt, *Lw = w.Lw;
@@ -215,15 +263,33 @@ __device__ int gi_solve(int n, int mt, int meq, QPWork& w, double* lam, int* ite
     }
     g_sync();
     if (stamp && gl == 0) stamp[1] = __builtin_amdgcn_s_memtime();
-    double s[MPL], sgn[MPL];
+    // FAST: one problem per wave and n <= NMAX.  Loops over the n variables run in unrolled chunks with
+    // clamped addresses (a chunk's loads are in flight together), group broadcasts are v_readlane, and the
+    // primal step keeps its direction in registers instead of LDS.
+    constexpr bool FAST = GS == 64 && NMAX > 0;
+    constexpr int UNR = 4;   // loads in flight per chunk of the n-loops
+    double s[MPL], sgn[MPL], iscale[MPL];
     unsigned amask = 0;
 #pragma unroll
     for (int sl = 0; sl < MPL; ++sl) {
         const int i = gl + sl * GS;
         double v = 0.0;
+        iscale[sl] = 1.0;
         if (i < mt) {
             v = hv[i];
-            for (int k = 0; k < n; ++k) v += Nt[k * mt + i] * xt[k];
+            iscale[sl] = 1.0 / (1.0 + fabs(v));
+            if constexpr (FAST) {
+                for (int k0 = 0; k0 < n; k0 += UNR) {
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) {
+                        const int k = k0 + u, kk = k < n ? k : n - 1;
+                        const double a = Nt[kk * mt + i], x = xt[kk];
+                        v = fma(k < n ? a : 0.0, x, v);
+                    }
+                }
+            } else {
+                for (int k = 0; k < n; ++k) v += Nt[k * mt + i] * xt[k];
+            }
         }
         s[sl] = v; sgn[sl] = 1.0;
     }
@@ -255,7 +321,7 @@ __device__ int gi_solve(int n, int mt, int meq, QPWork& w, double* lam, int* ite
             for (int sl = 0; sl < MPL; ++sl) {
                 const int i = gl + sl * GS;
                 if (i < mt && i >= meq && !(amask >> sl & 1u)) {
-                    const double sc = s[sl] / (1.0 + fabs(hv[i]));
+                    const double sc = s[sl] * iscale[sl];
                     if (sc < best) { best = sc; bi = i; }
                 }
             }
@@ -271,26 +337,66 @@ __device__ int gi_solve(int n, int mt, int meq, QPWork& w, double* lam, int* ite
         for (;;) {
             if (++iters > max_iter) { status = 1; break; }
             double kp = 0.0, kpp = 0.0;
-            for (int k = 0; k < n; ++k) {
-                const double np_k = Nt[k * mt + p];
-                kpp += np_k * np_k;
-                if (gl < q) kp += Nt[k * mt + wj] * np_k;
+            if constexpr (FAST) {
+                const int wc = gl < q ? wj : p;
+                for (int k0 = 0; k0 < n; k0 += UNR) {
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) {
+                        const int k = k0 + u, kk = k < n ? k : n - 1;
+                        double np_k = Nt[kk * mt + p];
+                        const double nw = Nt[kk * mt + wc];
+                        np_k = k < n ? np_k : 0.0;
+                        kpp = fma(np_k, np_k, kpp);
+                        kp = fma(nw, np_k, kp);
+                    }
+                }
+                kp = gl < q ? kp : 0.0;
+            } else {
+                for (int k = 0; k < n; ++k) {
+                    const double np_k = Nt[k * mt + p];
+                    kpp += np_k * np_k;
+                    if (gl < q) kp += Nt[k * mt + wj] * np_k;
+                }
             }
             // l = Lw^-1 kp
             double v = kp, lj = 0.0;
-            for (int i = 0; i < q; ++i) {
-                const double li = g_bcast<GS>(v, i) * w.invdW[i];
-                if (gl == i) lj = li;
-                if (gl > i && gl < q) v -= Lw[gl * n + i] * li;
+            const int glq = gl < q ? gl : 0;                     // in-range row / column of Lw for idle lanes
+            const double invw = FAST ? w.invdW[glq] : 0.0;       // lane i: 1 / Lw[i][i]
+            if constexpr (FAST) {
+                double lnext = Lw[glq * n];
+                for (int i = 0; i < q; ++i) {
+                    const double lcur = lnext;
+                    if (i + 1 < q) lnext = Lw[glq * n + i + 1];
+                    const double li = readlane_d(v, i) * readlane_d(invw, i);
+                    if (gl == i) lj = li;
+                    if (gl > i && gl < q) v = fma(-lcur, li, v);
+                }
+            } else {
+                for (int i = 0; i < q; ++i) {
+                    const double li = g_bcast<GS>(v, i) * w.invdW[i];
+                    if (gl == i) lj = li;
+                    if (gl > i && gl < q) v -= Lw[gl * n + i] * li;
+                }
             }
             const double dd = kpp - g_sum<GS>(gl < q ? lj * lj : 0.0);
             // r = Lw^-T l
             v = lj;
             double rj = 0.0;
-            for (int i = q - 1; i >= 0; --i) {
-                const double ri = g_bcast<GS>(v, i) * w.invdW[i];
-                if (gl == i) rj = ri;
-                if (gl < i) v -= Lw[i * n + gl] * ri;
+            if constexpr (FAST) {
+                double lnext = q > 0 ? Lw[(q - 1) * n + glq] : 0.0;
+                for (int i = q - 1; i >= 0; --i) {
+                    const double lcur = lnext;
+                    if (i > 0) lnext = Lw[(i - 1) * n + glq];
+                    const double ri = readlane_d(v, i) * readlane_d(invw, i);
+                    if (gl == i) rj = ri;
+                    if (gl < i) v = fma(-lcur, ri, v);
+                }
+            } else {
+                for (int i = q - 1; i >= 0; --i) {
+                    const double ri = g_bcast<GS>(v, i) * w.invdW[i];
+                    if (gl == i) rj = ri;
+                    if (gl < i) v -= Lw[i * n + gl] * ri;
+                }
             }
             double t1 = QP_INF; int kd = 0x7fffffff;
             if (gl < q && wj >= meq && rj > 1e-13) { t1 = lamj / rj; kd = gl; }
@@ -300,22 +406,45 @@ __device__ int gi_solve(int n, int mt, int meq, QPWork& w, double* lam, int* ite
             const double t = t1 < t2 ? t1 : t2;
             if (!(t < QP_INF)) { status = 2; break; }
             if (primal) {
-                g_sync();
-                if (gl < q) { w.rW[gl] = rj; w.Wl[gl] = wj; }
-                g_sync();
-                for (int k = gl; k < n; k += GS) {
-                    double a = Nt[k * mt + p];
-                    for (int j = 0; j < q; ++j) a -= Nt[k * mt + w.Wl[j]] * w.rW[j];
-                    w.vv[k] = a;
-                }
-                g_sync();
+                if constexpr (FAST) {
+                    // lane k < n: component k of the primal direction v = nt_p - Nt_W r
+                    const int kr = gl < n ? gl : n - 1;
+                    double a = Nt[kr * mt + p];
+                    for (int j = 0; j < q; ++j)
+                        a = fma(-Nt[kr * mt + __builtin_amdgcn_readlane(wj, j)], readlane_d(rj, j), a);
 #pragma unroll
-                for (int sl = 0; sl < MPL; ++sl) {
-                    const int i = gl + sl * GS;
-                    if (i < mt) {
+                    for (int sl = 0; sl < MPL; ++sl) {
+                        const int i = gl + sl * GS;
+                        const int ic = i < mt ? i : mt - 1;
                         double dot = 0.0;
-                        for (int k = 0; k < n; ++k) dot += Nt[k * mt + i] * w.vv[k];
-                        s[sl] += t * dot;
+                        for (int k0 = 0; k0 < n; k0 += UNR) {
+#pragma unroll
+                            for (int u = 0; u < UNR; ++u) {
+                                const int k = k0 + u, kk = k < n ? k : n - 1;
+                                const double nk = Nt[kk * mt + ic];
+                                dot = fma(k < n ? nk : 0.0, readlane_d(a, kk), dot);
+                            }
+                        }
+                        if (i < mt) s[sl] = fma(t, dot, s[sl]);
+                    }
+                } else {
+                    g_sync();
+                    if (gl < q) { w.rW[gl] = rj; w.Wl[gl] = wj; }
+                    g_sync();
+                    for (int k = gl; k < n; k += GS) {
+                        double a = Nt[k * mt + p];
+                        for (int j = 0; j < q; ++j) a -= Nt[k * mt + w.Wl[j]] * w.rW[j];
+                        w.vv[k] = a;
+                    }
+                    g_sync();
+#pragma unroll
+                    for (int sl = 0; sl < MPL; ++sl) {
+                        const int i = gl + sl * GS;
+                        if (i < mt) {
+                            double dot = 0.0;
+                            for (int k = 0; k < n; ++k) dot += Nt[k * mt + i] * w.vv[k];
+                            s[sl] += t * dot;
+                        }
                     }
                 }
             }
@@ -340,8 +469,8 @@ __device__ int gi_solve(int n, int mt, int meq, QPWork& w, double* lam, int* ite
                 const int dropped = g_bcast_i<GS>(wj, kd);
 #pragma unroll
                 for (int sl = 0; sl < MPL; ++sl) if (gl + sl * GS == dropped) amask &= ~(1u << sl);
-                const double lnext = g_bcast<GS>(lamj, (gl + 1) & (GS - 1));
-                const int wnext = g_bcast_i<GS>(wj, (gl + 1) & (GS - 1));
+                const double lnext = g_next<GS>(lamj);
+                const int wnext = g_next_i<GS>(wj);
                 if (gl >= kd && gl < q - 1) { lamj = lnext; wj = wnext; }
                 --q;
                 if (gl >= q) { lamj = 0.0; wj = -1; }
@@ -369,15 +498,30 @@ __device__ int gi_solve(int n, int mt, int meq, QPWork& w, double* lam, int* ite
     if (stamp && gl == 0) stamp[3] = __builtin_amdgcn_s_memtime();
     // z:  L' z = zt_unc + Nt_W lam
     g_sync();
-    if (gl < q) { w.lamW[gl] = lamj; w.Wl[gl] = wj; }
-    g_sync();
-    for (int k = gl; k < n; k += GS) {
-        double a = xt[k];
-        for (int j = 0; j < q; ++j) a += Nt[k * mt + w.Wl[j]] * w.lamW[j];
-        w.vv[k] = a;
-    }
-    g_sync();
-    {
+    if constexpr (FAST) {
+        const int kr = gl < n ? gl : n - 1;
+        double v = xt[kr];
+        for (int j = 0; j < q; ++j) v = fma(Nt[kr * mt + __builtin_amdgcn_readlane(wj, j)], readlane_d(lamj, j), v);
+        const double invl = w.invdL[kr];
+        double xres = 0.0, lnext = Lm[(n - 1) * n + kr];
+        for (int i = n - 1; i >= 0; --i) {
+            const double lcur = lnext;
+            if (i > 0) lnext = Lm[(i - 1) * n + kr];
+            const double xi = readlane_d(v, i) * readlane_d(invl, i);
+            if (gl == i) xres = xi;
+            if (gl < i) v = fma(-lcur, xi, v);
+        }
+        g_sync();
+        if (gl < n) xt[gl] = xres;
+    } else {
+        if (gl < q) { w.lamW[gl] = lamj; w.Wl[gl] = wj; }
+        g_sync();
+        for (int k = gl; k < n; k += GS) {
+            double a = xt[k];
+            for (int j = 0; j < q; ++j) a += Nt[k * mt + w.Wl[j]] * w.lamW[j];
+            w.vv[k] = a;
+        }
+        g_sync();
         double v = gl < n ? w.vv[gl] : 0.0, xres = 0.0;
         for (int i = n - 1; i >= 0; --i) {
             const double xi = g_bcast<GS>(v, i) * w.invdL[i];
