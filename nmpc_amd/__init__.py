@@ -2,7 +2,7 @@
 from ._lib import NmpcError, LIB_PATH  # noqa: F401
 from .model import Encoder, Norm, load_system, DISC_WEIGHTS  # noqa: F401
 from .lpv import (Jacobian, jacobians, quad_nodes, embed, lpv_int, lpv_int_C, lambda_simpson,  # noqa: F401
-                  lambda_trap, par_lpv_int)
+                  lambda_trap, par_lpv_int, MappedGet, mapped_get, getABlist, getABClist, getClist)
 from .mpcutil import getPhi, getGamma, getF0, getZ, getPsi, getOmega, getDEMc, getDEMc_out  # noqa: F401
 from .qp import solve_qp  # noqa: F401
 from .nmpc import OutputUnbalancedDisc, Controller, mpc_qp, output_NMPC_linear  # noqa: F401

@@ -108,3 +108,81 @@ def par_lpv_int(x, nx, u, nu, Jfx, Jfu, dlam, stages, L):
     wts = np.concatenate([np.full(stages, 1.0), np.full(stages, 4.0), np.full(stages, 1.0)]) * (1 / 6 * dlam)
     A, B, _ = embed(Jfx.model, x, u, None, *_merge(L, wts))
     return A, B
+
+
+class MappedGet:
+    """Stands for the reference's horizon-mapped CasADi functions Get_A / Get_B / Get_C
+    (`Function(...).map(Nc, "thread", 32)`, NMPC.py:82-86, NMPC_output.py:72-80): called with the
+    scheduling states X [..., nx, Nc] (column k = x_k) and inputs u [..., Nc] it returns the Nc
+    matrices side by side, [..., rows, Nc*cols], as the mapped function does."""
+
+    def __init__(self, model, which, lam, w):
+        assert which in ("A", "B", "C")
+        self.model, self.which = model, which
+        self.lam = np.ascontiguousarray(lam, np.float32)
+        self.w = np.ascontiguousarray(w, np.float32)
+
+    def __call__(self, X, u=None):
+        m = self.model
+        X = torch.as_tensor(X)
+        pts = X.transpose(-1, -2)                                   # [..., Nc, nx]
+        if self.which == "C":
+            out = embed(m, None, None, pts, self.lam, self.w)[2]   # [..., Nc, ny, nx]
+        else:
+            uu = torch.as_tensor(u).reshape(pts.shape[:-1] + (m.nu,))
+            out = embed(m, pts, uu, None, self.lam, self.w)[0 if self.which == "A" else 1]
+        Nc = out.shape[-3]
+        return out.transpose(-3, -2).reshape(out.shape[:-3] + (out.shape[-2], Nc * out.shape[-1]))
+
+
+def mapped_get(model, rule="simpson", stages=20, dlam=None):
+    """(Get_A, Get_B, Get_C) for a model and quadrature rule (lambda_simpson: NMPC_output.py:72)."""
+    lam, w = quad_nodes(rule, stages, dlam)
+    return tuple(MappedGet(model, k, lam, w) for k in "ABC")
+
+
+def _split_states(x, Nc, nx):
+    """np.vstack(np.split(x, Nc)).T of the reference: stacked [.., Nc*nx(,1)] -> [.., nx, Nc]"""
+    x = torch.as_tensor(x)
+    if x.shape[-1] == 1 and x.dim() >= 2 and x.shape[-2] == Nc * nx:
+        x = x[..., 0]
+    return x.reshape(x.shape[:-1] + (Nc, nx)).transpose(-1, -2)
+
+
+def _fill(dst, p, Nc, rows, cols):
+    """list[(rows*i):(rows*i+rows), :] = p[:, i*cols:(i+1)*cols] for every i (mpcUtil.py:138-139)"""
+    blocks = p.reshape(p.shape[:-1] + (Nc, cols)).transpose(-3, -2)          # [..., Nc, rows, cols]
+    src = blocks.reshape(p.shape[:-2] + (Nc * rows, cols)).to(dst.dtype)
+    dst.copy_(src.to(dst.device))
+    return dst
+
+
+def getABlist(x, u, Nc, nx, nu, Get_A, Get_B, list_A, list_B):
+    """mpcUtil.py:136-144: fills and returns the caller's list_A [..., Nc*nx, nx] and
+    list_B [..., Nc*nx, nu] (torch tensors, written in place) from the stacked states
+    x [..., Nc*nx(,1)] and inputs u [..., Nc]."""
+    X = _split_states(x, Nc, nx)
+    if isinstance(Get_A, MappedGet) and isinstance(Get_B, MappedGet) and Get_A.model is Get_B.model \
+            and np.array_equal(Get_A.lam, Get_B.lam) and np.array_equal(Get_A.w, Get_B.w):
+        m = Get_A.model                                              # one launch serves both
+        pts = X.transpose(-1, -2)
+        A, B, _ = embed(m, pts, torch.as_tensor(u).reshape(pts.shape[:-1] + (m.nu,)), None, Get_A.lam, Get_A.w)
+        list_A.copy_(A.reshape(A.shape[:-3] + (Nc * nx, nx)).to(list_A.dtype))
+        list_B.copy_(B.reshape(B.shape[:-3] + (Nc * nx, nu)).to(list_B.dtype))
+        return list_A, list_B
+    _fill(list_A, Get_A(X, u), Nc, nx, nx)
+    _fill(list_B, Get_B(X, u), Nc, nx, nu)
+    return list_A, list_B
+
+
+def getABClist(x, u, Nc, nx, nu, ny, Get_A, Get_B, Get_C, list_A, list_B, list_C):
+    """mpcUtil.py:147-158.  As in the reference, list_C is returned untouched (its fill is
+    commented out there, mpcUtil.py:154-156; callers use getClist with the shifted states)."""
+    getABlist(x, u, Nc, nx, nu, Get_A, Get_B, list_A, list_B)
+    return list_A, list_B, list_C
+
+
+def getClist(x, u, Nc, nx, ny, Get_C, list_C):
+    """mpcUtil.py:160-165: list_C [..., Nc*ny, nx] from the stacked states x."""
+    _fill(list_C, Get_C(_split_states(x, Nc, nx), u), Nc, ny, nx)
+    return list_C

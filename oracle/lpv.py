@@ -113,3 +113,18 @@ def lpv_rk4(x, u, A, B, dt, correction):
     rhs = lambda s: dt * (np.einsum("...ij,...j->...i", A, s) + bu)
     k1 = rhs(x); k2 = rhs(x + k1 / 2); k3 = rhs(x + k2 / 2); k4 = rhs(x + k3)
     return x + (k1 + 2 * k2 + 2 * k3 + k4) / 6
+
+
+def get_ab_list(model, x, u, Nc, nodes, weights):
+    """mpcUtil.py:136-144 getABlist: stacked states x[Nc*nx] (x_0 .. x_{Nc-1}) and inputs u[Nc] ->
+    list_A [Nc*nx, nx], list_B [Nc*nx, nu] (row block k = A_k / B_k at (x_k, u_k))."""
+    X = np.asarray(x, float).reshape(Nc, model.nx)
+    A, B, _ = embed(model, X, np.asarray(u, float).reshape(Nc, model.nu), nodes, weights)
+    return A.reshape(Nc * model.nx, model.nx), B.reshape(Nc * model.nx, model.nu)
+
+
+def get_c_list(model, x, Nc, nodes, weights):
+    """mpcUtil.py:160-165 getClist: list_C [Nc*ny, nx], row block k = C at the k-th stacked state."""
+    X = np.asarray(x, float).reshape(Nc, model.nx)
+    C = embed(model, X, np.zeros((Nc, model.nu)), nodes, weights)[2]
+    return C.reshape(Nc * model.ny, model.nx)

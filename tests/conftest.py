@@ -16,7 +16,7 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np
-    return {n: np.load(os.path.join(GOLDEN, "ref_%s.npz" % n)) for n in ("condense", "lpv", "jac")}
+    return {n: np.load(os.path.join(GOLDEN, "ref_%s.npz" % n)) for n in ("condense", "lpv", "jac", "ablist")}
 
 
 @pytest.fixture(scope="session")

@@ -127,3 +127,28 @@ def test_synthetic_nets(w2_scale):
         err = np.abs(got.cpu().numpy().astype(np.float64).reshape(ref.shape) - ref).max()
         assert err / np.abs(ref).max() < TOL
     assert relerr(A.cpu(), Ao) < TOL and relerr(C.cpu(), Co) < TOL
+
+
+def test_ablist_family_on_golden(enc, golden):
+    """getABlist / getABClist / getClist with the reference's signatures and in-place list buffers
+    (mpcUtil.py:136-165), batched and un-batched, against what the reference returned."""
+    import nmpc_amd
+    g = golden["ablist"]
+    Nc, nx, nu, ny = 10, 2, 1, 1
+    Get_A, Get_B, Get_C = nmpc_amd.mapped_get(enc, "simpson", 20)
+    x, u = torch.tensor(g["x"]), torch.tensor(g["u"])
+    lA = torch.zeros(3, Nc * nx, nx, dtype=torch.float64, device="cuda"); lB = torch.zeros(3, Nc * nx, nu, dtype=torch.float64, device="cuda")
+    lC = torch.full((3, Nc * ny, nx), 7.0, dtype=torch.float64, device="cuda")
+    rA, rB, rC = nmpc_amd.getABClist(x, u, Nc, nx, nu, ny, Get_A, Get_B, Get_C, lA, lB, lC)
+    assert rA is lA and rB is lB and rC is lC and bool((lC == 7.0).all())
+    assert relerr(lA.cpu(), g["list_A"]) < TOL and relerr(lB.cpu(), g["list_B"]) < TOL
+    nmpc_amd.getClist(x, u, Nc, nx, ny, Get_C, lC)
+    assert relerr(lC.cpu(), g["list_C"]) < TOL
+    # un-batched, separate (non-fused) Get_A / Get_B path, fp32 buffers
+    a1 = torch.zeros(Nc * nx, nx, device="cuda"); b1 = torch.zeros(Nc * nx, nu, device="cuda")
+    GA2 = nmpc_amd.MappedGet(enc, "A", *nmpc_amd.quad_nodes("simpson", 20))
+    GB2 = nmpc_amd.MappedGet(enc, "B", *nmpc_amd.quad_nodes("trap", 20))
+    nmpc_amd.getABlist(x[1], u[1], Nc, nx, nu, GA2, GB2, a1, b1)
+    assert np.abs(a1.cpu().numpy() - g["list_A"][1]).max() < 1e-5
+    pA = Get_A(x[1].reshape(Nc, nx).T, u[1])
+    assert pA.shape == (nx, Nc * nx) and np.abs(pA[:, 2:4].cpu().numpy() - g["list_A"][1][2:4]).max() < 1e-5

@@ -98,6 +98,18 @@ def test_reference_named_entry_points(golden, omodel):
     assert np.allclose(A, l["int_A"][3], atol=1e-12)
 
 
+def test_ablist_golden(golden, omodel):
+    """getABlist / getClist of the reference (mpcUtil.py:136-165) on stacked states."""
+    g = golden["ablist"]
+    nodes, weights = lpv.merge_nodes(*lpv.quad_nodes("simpson", 20))
+    for b in range(g["x"].shape[0]):
+        lA, lB = lpv.get_ab_list(omodel, g["x"][b], g["u"][b], 10, nodes, weights)
+        lC = lpv.get_c_list(omodel, g["x"][b], 10, nodes, weights)
+        assert np.abs(lA - g["list_A"][b]).max() < 1e-12 and np.abs(lB - g["list_B"][b]).max() < 1e-12
+        assert np.abs(lC - g["list_C"][b]).max() < 1e-12
+    assert np.all(g["list_C_abc"] == 7.0)      # getABClist leaves list_C as passed (mpcUtil.py:154-158)
+
+
 def test_qp_kkt_and_scipy():
     from scipy.optimize import minimize
     rng = np.random.default_rng(0)

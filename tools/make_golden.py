@@ -15,6 +15,10 @@ Produces
                                  callables are torch.func jacrev of torch nets rebuilt from the
                                  raw weights (the mechanism of NMPC_test.py:137-138), fp64
   tests/golden/ref_jac.npz       vmap(jacrev) Jacobians of f, h at seeded points (fp64 torch)
+  tests/golden/ref_ablist.npz    getABlist/getABClist/getClist (mpcUtil.py:136-165) driven with NumPy
+                                 stand-ins of the horizon-mapped Get_A/Get_B/Get_C (lambda_simpson of the
+                                 reference on the jacrev callables, Nc results side by side)
+(`--only ablist` writes just the last file.)
 """
 import os
 import sys
@@ -55,11 +59,48 @@ def torch_nets(weights):
     return make("fn"), make("hn")
 
 
+def make_ablist(mpcUtil, lpv_int):
+    import torch
+    from torch.func import jacrev
+    fnet, hnet = torch_nets(os.path.join(ROOT, "nmpc_amd", "data", "disc_snr30.npz"))
+    nx, nu, ny, Nc, stages = 2, 1, 1, 10, 20
+    f_xu = lambda x, u: fnet(torch.cat([x, u]))
+    t = lambda v, n: torch.as_tensor(np.asarray(v, np.float64)).reshape(n)
+    Jfx = lambda x, u: jacrev(f_xu, argnums=0)(t(x, nx), t(u, nu)).numpy()
+    Jfu = lambda x, u: jacrev(f_xu, argnums=1)(t(x, nx), t(u, nu)).numpy()
+    Jhx = lambda x, u: jacrev(hnet)(t(x, nx)).numpy()
+
+    def mapped(k):        # what Function(...).map(Nc) returns: the Nc results side by side
+        def call(X, u):
+            u = np.asarray(u, np.float64).reshape(-1)
+            return np.hstack([lpv_int.lambda_simpson(X[:, i], u[i], nx, nu, ny, Jfx, Jfu, Jhx, stages)[k]
+                              for i in range(X.shape[1])])
+        return call
+    rng = np.random.default_rng(777)
+    B = 3
+    out = {"x": rng.uniform(-2, 2, (B, Nc * nx)), "u": rng.uniform(-2, 2, (B, Nc))}   # 1-D stacked states, as np.split needs
+    lA, lB, lC, lC2 = [], [], [], []
+    for b in range(B):
+        a, bb = mpcUtil.getABlist(out["x"][b], out["u"][b], Nc, nx, nu, mapped(0), mapped(1),
+                                  np.zeros((Nc * nx, nx)), np.zeros((Nc * nx, nu)))
+        c = mpcUtil.getClist(out["x"][b], out["u"][b], Nc, nx, ny, mapped(2), np.zeros((Nc * ny, nx)))
+        _, _, c2 = mpcUtil.getABClist(out["x"][b], out["u"][b], Nc, nx, nu, ny, mapped(0), mapped(1), mapped(2),
+                                      np.zeros((Nc * nx, nx)), np.zeros((Nc * nx, nu)), np.full((Nc * ny, nx), 7.0))
+        lA.append(a); lB.append(bb); lC.append(c); lC2.append(c2)
+    out.update(list_A=np.array(lA), list_B=np.array(lB), list_C=np.array(lC), list_C_abc=np.array(lC2))
+    np.savez_compressed(os.path.join(OUT, "ref_ablist.npz"), **out)
+
+
 def main():
     import torch
     from torch.func import jacrev, vmap
     mpcUtil, lpv_int, lpv_rk4 = load_reference()
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:3] == ["--only", "ablist"]:
+        make_ablist(mpcUtil, lpv_int)
+        print("wrote ref_ablist.npz")
+        return
+    make_ablist(mpcUtil, lpv_int)
     rng = np.random.default_rng(20240607)
 
     # ---- condensing ------------------------------------------------------------------
