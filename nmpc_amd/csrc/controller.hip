@@ -30,24 +30,25 @@ struct MpcConst {
 // LDS carve for one controller's condensing + QP
 struct MpcLds {
     QPWork qp;
-    double *Ak, *Bk, *Ck, *Pk, *Sk, *xi, *Gam, *x0, *Xs, *Us, *uold;
+    double *Ak, *Bk, *Ck, *qd, *xi, *Gam, *x0, *Xs, *Us, *uold;
+    // Gam holds the block lower triangle of Gamma, packed: block (i, j <= i) at ((i (i+1))/2 + j) * nx
+    __device__ static int tri(int i, int j) { return i * (i + 1) / 2 + j; }
     __device__ void carve(double* base, int Nc, int nx) {
         const int n = Nc + 1, mt = 4 * Nc + 2;
         qp.carve(base, n, mt);
         double* p = base + qp_lds_doubles(n, mt);
         Ak = p; p += Nc * nx * nx; Bk = p; p += Nc * nx; Ck = p; p += Nc * nx;
-        Pk = p; p += Nc * nx * nx; Sk = p; p += Nc * nx * nx; xi = p; p += Nc * nx;
-        Gam = p; p += Nc * Nc * nx; x0 = p; p += nx; Xs = p; p += Nc * nx; Us = p; p += Nc; uold = p;
+        qd = p; p += Nc * nx; xi = p; p += Nc * nx;
+        Gam = p; p += Nc * (Nc + 1) / 2 * nx; x0 = p; p += nx; Xs = p; p += Nc * nx; Us = p; p += Nc; uold = p;
     }
 };
 __host__ __device__ inline int mpc_lds_doubles(int Nc, int nx) {
     const int n = Nc + 1, mt = 4 * Nc + 2;
-    return qp_lds_doubles(n, mt) + 2 * Nc * nx * nx + Nc * nx * nx + 5 * Nc * nx + Nc * Nc * nx + nx + 2 * Nc + 2;
+    return qp_lds_doubles(n, mt) + Nc * nx * nx + 5 * Nc * nx + Nc * (Nc + 1) / 2 * nx + nx + 2 * Nc + 2;
 }
 
 // Fills qp.Lm (Hessian, lower triangle), qp.xt (linear term), qp.Nt / qp.hv (constraint rows) from
-// Ak, Bk, Ck, x0, Xs, Us.  Leaves xi and Gam for mpc_predict.  Uses Sk[0 .. Nc*NX) as scratch for
-// Q (xi_i - Xs_i).
+// Ak, Bk, Ck, x0, Xs, Us.  Leaves xi and Gam for mpc_predict.
 //
 // Condensing runs as independent recurrences, one per lane and entirely in registers (the only
 // LDS traffic on the critical path is the broadcast read of A_d):
@@ -60,11 +61,10 @@ __host__ __device__ inline int mpc_lds_doubles(int Nc, int nx) {
 template <int GS, int NX, int NC = 0>
 __device__ __forceinline__ void mpc_assemble(const MpcConst& c, MpcLds& L, double ymeas, int gl, unsigned long long* st = nullptr) {
     const int Nc = NC ? NC : c.Nc, n = Nc + 1, mt = 4 * Nc + 2;   // NC > 0: horizon known at compile time
-    double* Lm = L.qp.Lm; double* Nt = L.qp.Nt; double* qd = L.Sk;
+    double* Lm = L.qp.Lm; double* Nt = L.qp.Nt; double* qd = L.qd;      // Q (xi_i - Xs_i)
     if (st && gl == 0) st[8] = __builtin_amdgcn_s_memtime();
     for (int e = gl; e < n * n; e += GS) Lm[e] = e == n * n - 1 ? c.rho : 0.0;
     for (int e = gl; e < n * mt; e += GS) Nt[e] = e >= Nc * mt ? -1.0 : 0.0;      // slack column: -1 on every row
-    for (int e = gl; e < Nc * Nc * NX; e += GS) L.Gam[e] = 0.0;
     if (gl == 0) L.qp.xt[Nc] = 0.0;
     g_sync();
     if (st && gl == 0) st[9] = __builtin_amdgcn_s_memtime();
@@ -98,7 +98,7 @@ __device__ __forceinline__ void mpc_assemble(const MpcConst& c, MpcLds& L, doubl
         auto emit = [&](int d) {
             if (col && j + d < Nc) {
 #pragma unroll
-                for (int r = 0; r < NX; ++r) L.Gam[((j + d) * Nc + j) * NX + r] = v[r];
+                for (int r = 0; r < NX; ++r) L.Gam[MpcLds::tri(j + d, j) * NX + r] = v[r];
             }
             if (fr) {
 #pragma unroll
@@ -171,10 +171,14 @@ __device__ __forceinline__ void mpc_assemble(const MpcConst& c, MpcLds& L, doubl
         const int b_ = on ? t - a_ * (a_ + 1) / 2 : 0;
         double g = 0.0, f = 0.0;
 #pragma unroll UNR_I
-        for (int i = 0; i < Nc; ++i) {             // Gamma_{i,a} = 0 for i < a: uniform trip count
+        for (int i = 0; i < Nc; ++i) {             // Gamma_{i,a} = 0 for i < a: uniform trip count, clamped reads
             double ga[NX], gb[NX];
+            const int ic = i > a_ ? i : a_;          // b <= a <= ic: both blocks exist
 #pragma unroll
-            for (int r = 0; r < NX; ++r) { ga[r] = L.Gam[(i * Nc + a_) * NX + r]; gb[r] = L.Gam[(i * Nc + b_) * NX + r]; }
+            for (int r = 0; r < NX; ++r) {
+                ga[r] = L.Gam[MpcLds::tri(ic, a_) * NX + r]; gb[r] = L.Gam[MpcLds::tri(ic, b_) * NX + r];
+                ga[r] = i >= a_ ? ga[r] : 0.0;
+            }
 #pragma unroll
             for (int r = 0; r < NX; ++r) {
                 double qg = 0.0;
@@ -190,7 +194,7 @@ __device__ __forceinline__ void mpc_assemble(const MpcConst& c, MpcLds& L, doubl
             // y_{a+1} = C_a x_{a+1} + h0:  rows -/+ of block a+1 (the last block has its own two rows)
             double cg = 0.0;
 #pragma unroll
-            for (int r = 0; r < NX; ++r) cg = fma(L.Ck[a_ * NX + r], L.Gam[(a_ * Nc + b_) * NX + r], cg);
+            for (int r = 0; r < NX; ++r) cg = fma(L.Ck[a_ * NX + r], L.Gam[MpcLds::tri(a_, b_) * NX + r], cg);
             const int rowm = a_ + 1 < Nc ? 4 * (a_ + 1) + 2 : 4 * Nc;
             Nt[b_ * mt + rowm] = -cg;
             Nt[b_ * mt + rowm + 1] = cg;
@@ -228,7 +232,7 @@ __device__ __forceinline__ void mpc_predict(const MpcConst& c, MpcLds& L, int gl
     for (int e = gl; e < Nc * NX; e += GS) {
         const int i = e / NX, r = e % NX;
         double a = L.xi[e];
-        for (int j = 0; j <= i; ++j) a += L.Gam[(i * Nc + j) * NX + r] * L.qp.xt[j];
+        for (int j = 0; j <= i; ++j) a += L.Gam[MpcLds::tri(i, j) * NX + r] * L.qp.xt[j];
         L.xi[e] = a;
     }
     g_sync();
