@@ -142,6 +142,9 @@ int nmpc_ctrl_stats(nmpc_ctrl* c, long long* stats, void* stream);
  * duration in ms (arrays of 3), and clears the record. */
 int nmpc_ctrl_profile(nmpc_ctrl* c, int enable);
 int nmpc_ctrl_profile_read(nmpc_ctrl* c, int* launches, double* total_ms, void* stream);
+/* Same record, per step: ms[nsteps][3] = summed launch durations of steps k0 .. k0+nsteps-1 per kind
+ * (the getAB / solve / sim buckets of the reference's components_time, NMPC_test.py:152-300). */
+int nmpc_ctrl_profile_read_steps(nmpc_ctrl* c, int k0, int nsteps, double* ms, void* stream);
 
 /* ---- steady-state target selector (reference: mpcUtil.py:241-320 getXsUs_Cs, called pre-loop at
  * NMPC_test.py:79-80).  For every reference sample j, warm-started from sample j-1, iterate up to

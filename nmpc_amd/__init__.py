@@ -8,3 +8,4 @@ from .qp import solve_qp  # noqa: F401
 from .nmpc import OutputUnbalancedDisc, Controller, mpc_qp, output_NMPC_linear  # noqa: F401
 from .target import GetABC, getXsUs_Cs  # noqa: F401
 from .lpvrk4 import lpv_rk4  # noqa: F401
+from .reference import stackReferences, randomLevelReference, random_level_batch, lpv_histogram, comp_time_stats  # noqa: F401

@@ -643,7 +643,7 @@ extern "C" int nmpc_mpc_qp(int nb, int Nc, int nx, const double* list_A, const d
     return dispatch_mpc_qp(a, g, (hipStream_t)stream);
 }
 
-struct ProfRec { hipEvent_t a, b; int kind; };
+struct ProfRec { hipEvent_t a, b; int kind, step; };
 
 // A slice is a contiguous range of the batch with its own stream, work lists and counters: the
 // controllers are independent, so slices advance through the step sequence concurrently and the
@@ -670,11 +670,11 @@ struct nmpc_ctrl {
     std::vector<ProfRec> prof_pool;   // idle pairs
 };
 
-static bool prof_begin(nmpc_ctrl* c, int kind, hipStream_t s, ProfRec& r) {
+static bool prof_begin(nmpc_ctrl* c, int kind, int step, hipStream_t s, ProfRec& r) {
     if (!c->prof_on) return false;
     if (!c->prof_pool.empty()) { r = c->prof_pool.back(); c->prof_pool.pop_back(); }
     else if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return false;
-    r.kind = kind;
+    r.kind = kind; r.step = step;
     return hipEventRecord(r.a, s) == hipSuccess;
 }
 static void prof_end(nmpc_ctrl* c, bool on, hipStream_t s, ProfRec& r) {
@@ -831,15 +831,15 @@ extern "C" int nmpc_ctrl_run(nmpc_ctrl* c, int k0, int nsteps, const double* Xs,
                 a.npts = d.B * d.Nc; a.group = d.Nc;
                 if (it > 0) { a.count_dev = d.nact + it; a.act = d.act + (size_t)it * d.B; }
                 ProfRec pr;
-                bool on = prof_begin(c, 0, s, pr);
+                bool on = prof_begin(c, 0, k, s, pr);
                 if (embed_launch(c->m, a, c->nt, s, true)) return 1;
                 prof_end(c, on, s, pr);
-                on = prof_begin(c, 1, s, pr);
+                on = prof_begin(c, 1, k, s, pr);
                 if (dispatch_mpc_solve(d, rp, it, k, c->g, s)) return 1;
                 prof_end(c, on, s, pr);
             }
             ProfRec pr;
-            const bool on = prof_begin(c, 2, s, pr);
+            const bool on = prof_begin(c, 2, k, s, pr);
             const int threads = 64 * PLANT_WAVES, grid = (d.B + PLANT_WAVES - 1) / PLANT_WAVES;
             if (d.nx == 2) hipLaunchKernelGGL((plant_kernel<2>), dim3(grid), dim3(threads), 0, s, d, rp, k);
             else if (d.nx == 3) hipLaunchKernelGGL((plant_kernel<3>), dim3(grid), dim3(threads), 0, s, d, rp, k);
@@ -870,6 +870,20 @@ extern "C" int nmpc_ctrl_profile_read(nmpc_ctrl* c, int* launches, double* total
         float ms = 0.f;
         NMPC_HIP_CHECK(hipEventElapsedTime(&ms, r.a, r.b));
         launches[r.kind] += 1; total_ms[r.kind] += ms;
+        c->prof_pool.push_back(r);
+    }
+    c->prof.clear();
+    return 0;
+}
+
+extern "C" int nmpc_ctrl_profile_read_steps(nmpc_ctrl* c, int k0, int nsteps, double* ms, void* stream) {
+    NMPC_REQUIRE(c && ms && nsteps >= 0, "nmpc_ctrl_profile_read_steps: bad argument");
+    NMPC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    for (int i = 0; i < 3 * nsteps; ++i) ms[i] = 0.0;
+    for (ProfRec& r : c->prof) {
+        float t = 0.f;
+        NMPC_HIP_CHECK(hipEventElapsedTime(&t, r.a, r.b));
+        if (r.step >= k0 && r.step < k0 + nsteps) ms[3 * (r.step - k0) + r.kind] += t;
         c->prof_pool.push_back(r);
     }
     c->prof.clear();

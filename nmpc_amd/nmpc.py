@@ -145,6 +145,15 @@ class Controller:
             check(lib().nmpc_ctrl_profile_read(self.handle, n, ms, current_stream()), "nmpc_ctrl_profile_read")
         return {k: (int(n[i]), float(ms[i])) for i, k in enumerate(("embed", "solve", "plant"))}
 
+    def profile_read_steps(self, k0, nsteps):
+        """[nsteps, 3] ms per step and kind (embed, solve, plant) since the last read."""
+        ms = np.zeros((nsteps, 3))
+        with torch.cuda.device(self.encoder.device):
+            check(lib().nmpc_ctrl_profile_read_steps(self.handle, int(k0), int(nsteps),
+                                                     ms.ctypes.data_as(_lib.c_double_p), current_stream()),
+                  "nmpc_ctrl_profile_read_steps")
+        return ms
+
     def stats(self):
         """(failed QP solves, QP solves, active-set iterations) since reset; synchronises."""
         v = (ctypes.c_longlong * 3)()
@@ -206,6 +215,7 @@ def output_NMPC_linear(system, encoder, u_min, u_max, y_min, y_max, x0, Q, R, dt
     torch.cuda.synchronize(dev)
     start = time.time()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(Nsim + 1)]
+    ctrl.profile(1)
     ev[0].record()
     for k in range(Nsim):
         ctrl.run(k, 1)
@@ -222,7 +232,16 @@ def output_NMPC_linear(system, encoder, u_min, u_max, y_min, y_max, x0, Q, R, dt
     x_log = x_log.reshape(B, (Nsim + 1) * nx)
     e_log = torch.zeros(B, nx, Nsim, dtype=torch.float64, device=dev); e_log[:, 0, :] = L["e_log"]
     t = np.arange(Nsim) * dt
+    # buckets of the reference (NMPC_test.py:152-300): getAB, solve, overhead, sim.  Column
+    # k*max_iterations holds step k, so that the reference's analysis (split into Nsim groups of
+    # max_iterations columns and sum, CompTime.ipynb cells 3-4) recovers per-step totals.
     components_time = np.zeros((4, Nsim * max_iterations))
+    kms = ctrl.profile_read_steps(0, Nsim) * 1e-3
+    ctrl.profile(0)
+    components_time[0, ::max_iterations] = kms[:, 0]
+    components_time[1, ::max_iterations] = kms[:, 1]
+    components_time[3, ::max_iterations] = kms[:, 2]
+    components_time[2, ::max_iterations] = np.maximum(comp_t_log - kms.sum(1), 0.0)
     out = [x_log, L["u_log"], e_log, comp_t_log, t, runtime, L["lpv_counter"], components_time, L["y_log"],
            L["y_est_log"], Xs, Us]
     if single:

@@ -127,6 +127,12 @@ def test_closed_loop_reference_file_config1(enc, omodel):
     out = nmpc_amd.output_NMPC_linear(plant, enc, -4, 4, [-1.2], [1.2], np.zeros(2), Q, 1.0, 0.1, 0.05, 20, yref, Nc=10, Nsim=Nsim,
                                       max_iterations=4)
     assert out[1].shape == (Nsim,) and out[0].shape == ((Nsim + 1) * 2,) and out[8].shape == (Nsim + 1,)
+    # timing logs in the reference's format feed its statistics (CompTime.ipynb)
+    ct, comp_t = out[7], out[3]
+    assert ct.shape == (4, Nsim * 4) and np.all(ct[0, ::4] > 0) and np.all(ct[1, ::4] > 0) and np.all(ct[3, ::4] > 0)
+    mx, top5, mean, std, solver = nmpc_amd.comp_time_stats(ct, Nsim)
+    assert 0 < solver < mean <= mx and abs(mean * 1e-3 - ct.sum() / Nsim) < 1e-12 and mean * 1e-3 <= comp_t.mean() * 1.5
+    assert sum(nmpc_amd.lpv_histogram(out[6]).values()) == Nsim
     assert np.abs(out[8].cpu().numpy() - o["y_log"]).max() < 1e-4
     assert np.abs(out[1].cpu().numpy() - o["u_log"]).max() < 1e-4
     assert (out[6].cpu().numpy() == o["lpv_counter"]).mean() > 0.99
