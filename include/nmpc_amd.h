@@ -114,6 +114,15 @@ typedef struct nmpc_ctrl_config {
     double plant[6];                     /* unbalanced disc g, J, Km, I, M, tau (Systems.py:82-87) */
     int n_nodes;
     float lam[NMPC_MAX_NODES], w[NMPC_MAX_NODES];
+    /* mode 0: output feedback with observer (output_NMPC_linear, NMPC_test.py:22-320).
+     * mode 1: state feedback (par_NMPC_linear / NMPC_linear, NMPC.py:374-650): the measured plant state
+     * is x0, box constraints x_min..x_max (normalised) act on measured and predicted states through
+     * getDEMc (mpcUtil.py:112-134), y_min/y_max are unused, the model offset f(0,0) is dropped;
+     * hard = 1 removes the slack variable (NMPC_linear's quadprog QP).  x_norm0 / x_normstd: the state
+     * normalisation vectors (norm.y0, norm.ystd of a full-state model). */
+    int mode, hard;
+    double x_min[4], x_max[4];
+    double x_norm0[4], x_normstd[4];
 } nmpc_ctrl_config;
 
 int nmpc_ctrl_create(nmpc_ctrl** out, const nmpc_model* m, const nmpc_ctrl_config* cfg);
@@ -122,7 +131,7 @@ void nmpc_ctrl_destroy(nmpc_ctrl* c);
  * state, u0n normalised initial input, plant_x0[2] (host, may be NULL = 0). */
 int nmpc_ctrl_reset(nmpc_ctrl* c, const double* x0n, double u0n, const double* plant_x0, void* stream);
 /* Steps k0 .. k0+nsteps-1.  Xs[batch,n_sim+Nc,nx], Us[batch,n_sim+Nc] steady-state targets;
- * noise[n_sim,batch] measurement noise (may be NULL).  Logs (device fp64 / int32, may be NULL):
+ * noise[n_sim,batch] measurement noise (mode 1: [n_sim,batch,nx]; may be NULL).  Logs (device fp64 / int32, may be NULL):
  * x_log[batch,n_sim+1,nx] u_log[batch,n_sim] e_log[batch,n_sim] y_log[batch,n_sim+1]
  * y_est_log[batch,n_sim+1] lpv_counter[batch,n_sim] plan_log[batch,n_sim,Nc]; entries k+1 (x, y, y_est)
  * and k (others) are written for every step k run. */
@@ -160,6 +169,14 @@ int nmpc_target_select(const nmpc_model* m, int nb, int nsamp, const double* y_r
                        double u_max, double y_min, double y_max, const float* lam, const float* w,
                        int n_nodes, int max_lpv, double tol, double* Xs, double* Us, double* Es,
                        int* iters, int* status, void* stream);
+/* State-constrained selector (reference: mpcUtil.py:167-239 getXsUs, called at NMPC.py:541-542): the
+ * same iteration with A, B only, a fixed output row C[nx] (host), equality offsets f0[nx] (host; NULL =
+ * the model's f(0,0)) and h0, and the soft box -u, u, -xs, xs (x_min[nx], x_max[nx], host, normalised). */
+int nmpc_target_select_state(const nmpc_model* m, int nb, int nsamp, const double* y_ref_n, double u_min,
+                             double u_max, const double* x_min, const double* x_max, const double* C,
+                             const double* f0, double h0, const float* lam, const float* w, int n_nodes,
+                             int max_lpv, double tol, double* Xs, double* Us, double* Es, int* iters,
+                             int* status, void* stream);
 
 #ifdef __cplusplus
 }

@@ -40,6 +40,10 @@ SIGNATURES = {
     "nmpc_ctrl_run": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int] + [c_void_p] * 11),
     "nmpc_target_select": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, c_void_p] + [ctypes.c_double] * 4 +
                            [c_float_p, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_double] + [c_void_p] * 6),
+    "nmpc_target_select_state": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, c_void_p, ctypes.c_double,
+                                                ctypes.c_double, c_double_p, c_double_p, c_double_p, c_double_p,
+                                                ctypes.c_double, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_double] + [c_void_p] * 6),
     "nmpc_ctrl_profile": (ctypes.c_int, [c_void_p, ctypes.c_int]),
     "nmpc_ctrl_profile_read": (ctypes.c_int, [c_void_p, c_int_p, c_double_p, c_void_p]),
     "nmpc_ctrl_profile_read_steps": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, c_double_p, c_void_p]),
@@ -58,7 +62,10 @@ class CtrlConfig(ctypes.Structure):
                 ("y_max", ctypes.c_double), ("u0", ctypes.c_double), ("ustd", ctypes.c_double),
                 ("y0", ctypes.c_double), ("ystd", ctypes.c_double), ("dt", ctypes.c_double),
                 ("plant", ctypes.c_double * 6), ("n_nodes", ctypes.c_int),
-                ("lam", ctypes.c_float * MAX_NODES), ("w", ctypes.c_float * MAX_NODES)]
+                ("lam", ctypes.c_float * MAX_NODES), ("w", ctypes.c_float * MAX_NODES),
+                ("mode", ctypes.c_int), ("hard", ctypes.c_int),
+                ("x_min", ctypes.c_double * 4), ("x_max", ctypes.c_double * 4),
+                ("x_norm0", ctypes.c_double * 4), ("x_normstd", ctypes.c_double * 4)]
 
 
 _lib = None

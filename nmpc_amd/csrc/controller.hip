@@ -20,12 +20,18 @@
 
 namespace nmpc {
 
+// mode 0: output feedback (rows -/+u_i, -/+y_i through C_k: getDEMc_out, mpcUtil.py:340-362);
+// mode 1: state feedback (rows -/+u_i, -/+x_i on the measured and predicted states: getDEMc,
+// mpcUtil.py:112-134).  slack = 1: one extra variable with weight rho and coefficient -1 on every row.
 struct MpcConst {
-    int Nc;
+    int Nc, mode, slack;
     double Q[16];
     double R, rho, umin, umax, ymin, ymax, h0;
     double f0[4];
+    double xmin[4], xmax[4];
 };
+__host__ __device__ inline int mpc_nvar(int Nc, int slack) { return Nc + (slack ? 1 : 0); }
+__host__ __device__ inline int mpc_nrows(int Nc, int nx, int mode) { return mode ? 2 * (nx + 1) * Nc + 2 * nx : 4 * Nc + 2; }
 
 // LDS carve for one controller's condensing + QP
 struct MpcLds {
@@ -33,8 +39,7 @@ struct MpcLds {
     double *Ak, *Bk, *Ck, *qd, *xi, *Gam, *x0, *Xs, *Us, *uold;
     // Gam holds the block lower triangle of Gamma, packed: block (i, j <= i) at ((i (i+1))/2 + j) * nx
     __device__ static int tri(int i, int j) { return i * (i + 1) / 2 + j; }
-    __device__ void carve(double* base, int Nc, int nx) {
-        const int n = Nc + 1, mt = 4 * Nc + 2;
+    __device__ void carve(double* base, int Nc, int nx, int n, int mt) {
         qp.carve(base, n, mt);
         double* p = base + qp_lds_doubles(n, mt);
         Ak = p; p += Nc * nx * nx; Bk = p; p += Nc * nx; Ck = p; p += Nc * nx;
@@ -42,8 +47,7 @@ struct MpcLds {
         Gam = p; p += Nc * (Nc + 1) / 2 * nx; x0 = p; p += nx; Xs = p; p += Nc * nx; Us = p; p += Nc; uold = p;
     }
 };
-__host__ __device__ inline int mpc_lds_doubles(int Nc, int nx) {
-    const int n = Nc + 1, mt = 4 * Nc + 2;
+__host__ __device__ inline int mpc_lds_doubles(int Nc, int nx, int n, int mt) {
     return qp_lds_doubles(n, mt) + Nc * nx * nx + 5 * Nc * nx + Nc * (Nc + 1) / 2 * nx + nx + 2 * Nc + 2;
 }
 
@@ -60,12 +64,14 @@ __host__ __device__ inline int mpc_lds_doubles(int Nc, int nx) {
 // carries F_a, and the same item writes the two y-rows' coefficient C_a Gamma_{a,b}.
 template <int GS, int NX, int NC = 0>
 __device__ __forceinline__ void mpc_assemble(const MpcConst& c, MpcLds& L, double ymeas, int gl, unsigned long long* st = nullptr) {
-    const int Nc = NC ? NC : c.Nc, n = Nc + 1, mt = 4 * Nc + 2;   // NC > 0: horizon known at compile time
+    // NC > 0: horizon known at compile time (output feedback with slack only)
+    const int Nc = NC ? NC : c.Nc, n = NC ? NC + 1 : mpc_nvar(Nc, c.slack), mt = NC ? 4 * NC + 2 : mpc_nrows(Nc, NX, c.mode);
+    const bool state_rows = NC ? false : c.mode != 0;
     double* Lm = L.qp.Lm; double* Nt = L.qp.Nt; double* qd = L.qd;      // Q (xi_i - Xs_i)
     if (st && gl == 0) st[8] = __builtin_amdgcn_s_memtime();
-    for (int e = gl; e < n * n; e += GS) Lm[e] = e == n * n - 1 ? c.rho : 0.0;
+    for (int e = gl; e < n * n; e += GS) Lm[e] = (n > Nc && e == n * n - 1) ? c.rho : 0.0;
     for (int e = gl; e < n * mt; e += GS) Nt[e] = e >= Nc * mt ? -1.0 : 0.0;      // slack column: -1 on every row
-    if (gl == 0) L.qp.xt[Nc] = 0.0;
+    if (gl == 0 && n > Nc) L.qp.xt[Nc] = 0.0;
     g_sync();
     if (st && gl == 0) st[9] = __builtin_amdgcn_s_memtime();
     // A_d is the same for every lane: with one controller per wave it is kept one entry per lane in
@@ -191,18 +197,46 @@ __device__ __forceinline__ void mpc_assemble(const MpcConst& c, MpcLds& L, doubl
         if (on) {
             Lm[a_ * n + b_] = 2.0 * (g + (a_ == b_ ? c.R : 0.0));
             if (a_ == b_) L.qp.xt[a_] = 2.0 * (f - c.R * L.Us[a_]);
-            // y_{a+1} = C_a x_{a+1} + h0:  rows -/+ of block a+1 (the last block has its own two rows)
-            double cg = 0.0;
+            if (!state_rows) {
+                // y_{a+1} = C_a x_{a+1} + h0:  rows -/+ of block a+1 (the last block has its own two rows)
+                double cg = 0.0;
 #pragma unroll
-            for (int r = 0; r < NX; ++r) cg = fma(L.Ck[a_ * NX + r], L.Gam[MpcLds::tri(a_, b_) * NX + r], cg);
-            const int rowm = a_ + 1 < Nc ? 4 * (a_ + 1) + 2 : 4 * Nc;
-            Nt[b_ * mt + rowm] = -cg;
-            Nt[b_ * mt + rowm + 1] = cg;
+                for (int r = 0; r < NX; ++r) cg = fma(L.Ck[a_ * NX + r], L.Gam[MpcLds::tri(a_, b_) * NX + r], cg);
+                const int rowm = a_ + 1 < Nc ? 4 * (a_ + 1) + 2 : 4 * Nc;
+                Nt[b_ * mt + rowm] = -cg;
+                Nt[b_ * mt + rowm + 1] = cg;
+            } else {
+                // x_{a+1}: rows -x (NX of them) then +x of block a+1; terminal rows after the last block
+                const int rowm = a_ + 1 < Nc ? 2 * (NX + 1) * (a_ + 1) + 2 : 2 * (NX + 1) * Nc;
+#pragma unroll
+                for (int r = 0; r < NX; ++r) {
+                    const double gv = L.Gam[MpcLds::tri(a_, b_) * NX + r];
+                    Nt[b_ * mt + rowm + r] = -gv;
+                    Nt[b_ * mt + rowm + NX + r] = gv;
+                }
+            }
         }
     }
     if (st && gl == 0) st[11] = __builtin_amdgcn_s_memtime();
     // rows 4i+{0,1}: -/+ u_i;  4i+{2,3}: -/+ y_i (y_0 measured);  last two: -/+ y_Nc
     for (int row = gl; row < mt; row += GS) {
+        if (state_rows) {
+            const int R6 = 2 * (NX + 1);
+            const int blk = row < R6 * Nc ? row / R6 : Nc;
+            const int kk = row < R6 * Nc ? row % R6 : 2 + (row - R6 * Nc);
+            double hval;
+            if (kk < 2) {
+                Nt[blk * mt + row] = kk ? 1.0 : -1.0;
+                hval = kk ? c.umax : -c.umin;
+            } else {
+                const int r = (kk - 2) % NX;
+                const bool up = kk - 2 >= NX;
+                const double xv = blk == 0 ? L.x0[r] : L.xi[(blk - 1) * NX + r];
+                hval = up ? c.xmax[r] - xv : xv - c.xmin[r];
+            }
+            L.qp.hv[row] = hval;
+            continue;
+        }
         const int blk = row < 4 * Nc ? row / 4 : Nc;
         const int kind = row < 4 * Nc ? row % 4 : 2 + (row - 4 * Nc);
         const double sg = (kind & 1) ? 1.0 : -1.0;
@@ -254,21 +288,21 @@ __global__ void mpc_qp_kernel(MpcQpArgs a) {
     const int gpb = blockDim.x / GS, g = threadIdx.x / GS, gl = threadIdx.x % GS;
     const int prob = blockIdx.x * gpb + g;
     if (prob >= a.nb) return;
-    const int Nc = NC ? NC : a.c.Nc, n = Nc + 1, mt = 4 * Nc + 2;
+    const int Nc = NC ? NC : a.c.Nc, n = NC ? NC + 1 : mpc_nvar(Nc, a.c.slack), mt = NC ? 4 * NC + 2 : mpc_nrows(Nc, NX, a.c.mode);
     MpcLds L;
-    L.carve(mpc_lds + (size_t)g * mpc_lds_doubles(Nc, NX), Nc, NX);
+    L.carve(mpc_lds + (size_t)g * mpc_lds_doubles(Nc, NX, n, mt), Nc, NX, n, mt);
     unsigned long long* st = a.stamps ? a.stamps + (size_t)prob * 12 : nullptr;
     if (st && gl == 0) st[0] = __builtin_amdgcn_s_memtime();
     for (int e = gl; e < Nc * NX * NX; e += GS) L.Ak[e] = a.lA[(size_t)prob * Nc * NX * NX + e];
     for (int e = gl; e < Nc * NX; e += GS) {
         L.Bk[e] = a.lB[(size_t)prob * Nc * NX + e];
-        L.Ck[e] = a.lC[(size_t)prob * Nc * NX + e];
+        L.Ck[e] = a.lC ? a.lC[(size_t)prob * Nc * NX + e] : 0.0;
         L.Xs[e] = a.Xs[(size_t)prob * Nc * NX + e];
     }
     for (int e = gl; e < Nc; e += GS) L.Us[e] = a.Us[(size_t)prob * Nc + e];
     for (int e = gl; e < NX; e += GS) L.x0[e] = a.x0[(size_t)prob * NX + e];
     g_sync();
-    mpc_assemble<GS, NX, NC>(a.c, L, a.ymeas[prob], gl, st);
+    mpc_assemble<GS, NX, NC>(a.c, L, a.ymeas ? a.ymeas[prob] : 0.0, gl, st);
     if (st && gl == 0) st[1] = __builtin_amdgcn_s_memtime();
     if (a.Ge) for (int e = gl; e < n * n; e += GS) a.Ge[(size_t)prob * n * n + e] = L.qp.Lm[e];
     if (a.Fe) for (int e = gl; e < n; e += GS) a.Fe[(size_t)prob * n + e] = L.qp.xt[e];
@@ -279,7 +313,7 @@ __global__ void mpc_qp_kernel(MpcQpArgs a) {
     if constexpr (GS == 64 && NC > 0 && NC + 1 <= 16) stt = gi_solve<GS, MPL, NC + 1>(n, mt, 0, L.qp, nullptr, nullptr, st ? st + 2 : nullptr);
     else stt = (GS == 64 && n <= 16) ? gi_solve<GS, MPL, (GS == 64 ? 16 : 0)>(n, mt, 0, L.qp, nullptr, nullptr, st ? st + 2 : nullptr)
                                      : gi_solve<GS, MPL>(n, mt, 0, L.qp, nullptr, nullptr, st ? st + 2 : nullptr);
-    const double epsv = L.qp.xt[Nc];
+    const double epsv = n > Nc ? L.qp.xt[Nc] : 0.0;
     mpc_predict<GS, NX, NC>(a.c, L, gl);
     if (st && gl == 0) st[7] = __builtin_amdgcn_s_memtime();
     if (a.u) for (int e = gl; e < Nc; e += GS) a.u[(size_t)prob * Nc + e] = L.qp.xt[e];
@@ -296,6 +330,7 @@ struct CtrlDev {
     double tol;
     MpcConst c;
     double u0, ustd, y0, ystd, dt;
+    double x0v[4], xstdv[4];   // state normalisation of the state-feedback mode (norm.y0, norm.ystd vectors)
     double plant[6];
     // state (fp64)
     double *x0n, *xpred, *uplan, *ymeas, *xp, *uhist, *yhist, *eps;
@@ -323,13 +358,14 @@ __global__ void mpc_solve_kernel(CtrlDev d, RunPtrs rp, int it, int k) {
     const int count = it == 0 ? d.B : min(d.nact[it], d.B);
     if (gid >= count) return;
     const int b = it == 0 ? gid : d.act[(size_t)it * d.B + gid];
-    const int Nc = NC ? NC : d.Nc, n = Nc + 1, mt = 4 * Nc + 2, ntot = d.n_sim + Nc;
+    const int Nc = NC ? NC : d.Nc, n = NC ? NC + 1 : mpc_nvar(Nc, d.c.slack), mt = NC ? 4 * NC + 2 : mpc_nrows(Nc, NX, d.c.mode);
+    const int ntot = d.n_sim + Nc;
     MpcLds L;
-    L.carve(mpc_lds + (size_t)g * mpc_lds_doubles(Nc, NX), Nc, NX);
+    L.carve(mpc_lds + (size_t)g * mpc_lds_doubles(Nc, NX, n, mt), Nc, NX, n, mt);
     for (int e = gl; e < Nc * NX * NX; e += GS) L.Ak[e] = (double)d.A32[(size_t)b * Nc * NX * NX + e];
     for (int e = gl; e < Nc * NX; e += GS) {
         L.Bk[e] = (double)d.B32[(size_t)b * Nc * NX + e];
-        L.Ck[e] = (double)d.C32[(size_t)b * Nc * NX + e];
+        L.Ck[e] = d.c.mode ? 0.0 : (double)d.C32[(size_t)b * Nc * NX + e];
         const int i = e / NX, r = e % NX;
         L.Xs[e] = rp.Xs[((size_t)b * ntot + (k + 1 + i)) * NX + r];
     }
@@ -345,7 +381,7 @@ __global__ void mpc_solve_kernel(CtrlDev d, RunPtrs rp, int it, int k) {
     if constexpr (GS == 64 && NC > 0 && NC + 1 <= 16) st = gi_solve<GS, MPL, NC + 1>(n, mt, 0, L.qp, nullptr, &qp_it);
     else st = (GS == 64 && n <= 16) ? gi_solve<GS, MPL, (GS == 64 ? 16 : 0)>(n, mt, 0, L.qp, nullptr, &qp_it)
                                     : gi_solve<GS, MPL>(n, mt, 0, L.qp, nullptr, &qp_it);
-    const double epsv = L.qp.xt[Nc];
+    const double epsv = n > Nc ? L.qp.xt[Nc] : 0.0;
     mpc_predict<GS, NX, NC>(d.c, L, gl);
     double du = 0.0;
     for (int e = gl; e < Nc; e += GS) {
@@ -508,6 +544,55 @@ __global__ __launch_bounds__(64 * PLANT_WAVES) void plant_kernel(CtrlDev d, RunP
     }
 }
 
+// State-feedback step (NMPC.py:484-495, 628-640): plant RK4, the measured state (plus noise
+// [n_sim, batch, NX]) becomes x0, logs, warm-start shift.  One thread per controller; the disc
+// plant has two states, so NX = 2.
+template <int NX>
+__global__ void plant_state_kernel(CtrlDev d, RunPtrs rp, int k) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0)
+        for (int it = 1; it <= d.maxit; ++it) d.nact[it] = 0;
+    if (b >= d.B) return;
+    const int Nc = d.Nc, ns = d.n_sim;
+    double* up = d.uplan + (size_t)b * Nc;
+    double* xpd = d.xpred + (size_t)b * Nc * NX;
+    const double u_den = d.ustd * up[0] + d.u0;
+    double w = d.xp[2 * b], th = d.xp[2 * b + 1];
+    double k1w, k1t, k2w, k2t, k3w, k3t, k4w, k4t;
+    disc_deriv(d.plant, w, th, u_den, k1w, k1t); k1w *= d.dt; k1t *= d.dt;
+    disc_deriv(d.plant, w + k1w / 2, th + k1t / 2, u_den, k2w, k2t); k2w *= d.dt; k2t *= d.dt;
+    disc_deriv(d.plant, w + k2w / 2, th + k2t / 2, u_den, k3w, k3t); k3w *= d.dt; k3t *= d.dt;
+    disc_deriv(d.plant, w + k3w, th + k3t, u_den, k4w, k4t); k4w *= d.dt; k4t *= d.dt;
+    w += (k1w + 2 * k2w + 2 * k3w + k4w) / 6;
+    th += (k1t + 2 * k2t + 2 * k3t + k4t) / 6;
+    d.xp[2 * b] = w; d.xp[2 * b + 1] = th;
+    const double xm[2] = {w + (rp.noise ? rp.noise[((size_t)k * rp.noise_ld + b) * NX] : 0.0),
+                          th + (rp.noise ? rp.noise[((size_t)k * rp.noise_ld + b) * NX + 1] : 0.0)};
+    double x0n[NX];
+#pragma unroll
+    for (int r = 0; r < NX; ++r) {
+        x0n[r] = (xm[r] - d.x0v[r]) / d.xstdv[r];
+        d.x0n[(size_t)b * NX + r] = x0n[r];
+        if (rp.x_log) rp.x_log[((size_t)b * (ns + 1) + k + 1) * NX + r] = xm[r];
+    }
+    if (rp.u_log) rp.u_log[(size_t)b * ns + k] = u_den;
+    if (rp.e_log) rp.e_log[(size_t)b * ns + k] = d.eps[b];
+    if (rp.lpv_counter) rp.lpv_counter[(size_t)b * ns + k] = d.cnt[b];
+    for (int i = 0; i < Nc; ++i) {
+        const double uv = up[i];
+        if (rp.plan_log) rp.plan_log[((size_t)b * ns + k) * Nc + i] = uv;
+        const double un = up[i + 1 < Nc ? i + 1 : Nc - 1];
+        up[i] = un;                                   // in order: entry i+1 is still the old value
+        d.us32[(size_t)b * Nc + i] = (float)un;
+    }
+    // predictions x_1..x_Nc shift by one state; scheduling states of the next pass: x0, x_2, .., x_Nc
+    for (int e = 0; e < Nc * NX; ++e) {
+        const double xv = xpd[e + NX < Nc * NX ? e + NX : e];
+        xpd[e] = xv;
+    }
+    for (int e = 0; e < Nc * NX; ++e) d.xs32[(size_t)b * Nc * NX + e] = e < NX ? (float)x0n[e] : (float)xpd[e - NX];
+}
+
 template <int NX>
 __global__ void reset_kernel(CtrlDev d, double u0n, double x0a, double x0b, double x0c, double x0d, double pw, double pth) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -543,18 +628,20 @@ static int pick_gs(int Nc) {
 
 // launch geometry shared by the stand-alone MPC QP and the closed-loop solve kernel
 struct MpcGeom { int GS, gpb, mpl; size_t lds; };
-static int mpc_geom(int Nc, int nx, MpcGeom& g) {
+static int mpc_geom(int Nc, int nx, int mode, int slack, MpcGeom& g) {
     NMPC_REQUIRE(Nc >= 1 && Nc + 1 <= 64, "horizon Nc=%d unsupported (1..63)", Nc);
     NMPC_REQUIRE(nx >= 1 && nx <= 4, "nx=%d unsupported by the MPC kernels (1..4)", nx);
     g.GS = pick_gs(Nc);
-    const size_t per = sizeof(double) * (size_t)mpc_lds_doubles(Nc, nx);
+    const int n = mpc_nvar(Nc, slack), mt = mpc_nrows(Nc, nx, mode);
+    NMPC_REQUIRE(mt <= 4 * 64, "horizon Nc=%d gives %d constraint rows (at most 256)", Nc, mt);
+    const size_t per = sizeof(double) * (size_t)mpc_lds_doubles(Nc, nx, n, mt);
     NMPC_REQUIRE(per * (64 / g.GS) <= 160 * 1024, "horizon Nc=%d needs %zu bytes of LDS per controller: too large", Nc, per);
     const int per_wave = 64 / g.GS;
     int waves = (int)((48 * 1024) / (per * per_wave));
     waves = waves < 1 ? 1 : (waves > 4 ? 4 : waves);
     g.gpb = waves * per_wave;
     g.lds = per * g.gpb;
-    g.mpl = (4 * Nc + 2 + g.GS - 1) / g.GS;
+    g.mpl = (mt + g.GS - 1) / g.GS;
     return 0;
 }
 
@@ -600,7 +687,7 @@ static int launch_mpc_solve(const CtrlDev& d, const RunPtrs& rp, int it, int k, 
 // The horizon of the reference's canonical configuration (Nc = 10, nx = 2: NMPC_test.py:326-344) has
 // kernels of its own with every loop bound a constant.
 static int dispatch_mpc_qp(const MpcQpArgs& a, const MpcGeom& g, hipStream_t s) {
-    if (a.nx == 2 && a.c.Nc == 10 && g.GS == 64 && g.mpl <= 1) return launch_mpc_qp<64, 1, 2, 10>(a, g, s);
+    if (a.nx == 2 && a.c.Nc == 10 && a.c.mode == 0 && a.c.slack && g.GS == 64 && g.mpl <= 1) return launch_mpc_qp<64, 1, 2, 10>(a, g, s);
     if (a.nx == 2) { NMPC_GEOM_SWITCH(launch_mpc_qp, 2, g, a, g, s) }
     if (a.nx == 3) { NMPC_GEOM_SWITCH(launch_mpc_qp, 3, g, a, g, s) }
     set_error("nmpc_mpc_qp: no kernel for nx=%d GS=%d rows/lane=%d", a.nx, g.GS, g.mpl);
@@ -608,7 +695,7 @@ static int dispatch_mpc_qp(const MpcQpArgs& a, const MpcGeom& g, hipStream_t s) 
 }
 
 static int dispatch_mpc_solve(const CtrlDev& d, const RunPtrs& rp, int it, int k, const MpcGeom& g, hipStream_t s) {
-    if (d.nx == 2 && d.Nc == 10 && g.GS == 64 && g.mpl <= 1) return launch_mpc_solve<64, 1, 2, 10>(d, rp, it, k, g, s);
+    if (d.nx == 2 && d.Nc == 10 && d.c.mode == 0 && d.c.slack && g.GS == 64 && g.mpl <= 1) return launch_mpc_solve<64, 1, 2, 10>(d, rp, it, k, g, s);
     if (d.nx == 2) { NMPC_GEOM_SWITCH(launch_mpc_solve, 2, g, d, rp, it, k, g, s) }
     if (d.nx == 3) { NMPC_GEOM_SWITCH(launch_mpc_solve, 3, g, d, rp, it, k, g, s) }
     set_error("nmpc_ctrl_run: no kernel for nx=%d GS=%d rows/lane=%d", d.nx, g.GS, g.mpl);
@@ -618,7 +705,7 @@ static int dispatch_mpc_solve(const CtrlDev& d, const RunPtrs& rp, int it, int k
 static void fill_const(MpcConst& c, int Nc, int nx, const double* Q, double R, double rho, double umin, double umax,
                        double ymin, double ymax, const double* f0, double h0) {
     std::memset(&c, 0, sizeof(c));
-    c.Nc = Nc;
+    c.Nc = Nc; c.mode = 0; c.slack = 1;
     for (int e = 0; e < nx * nx; ++e) c.Q[e] = Q[e];
     for (int r = 0; r < nx; ++r) c.f0[r] = f0[r];
     c.R = R; c.rho = rho; c.umin = umin; c.umax = umax; c.ymin = ymin; c.ymax = ymax; c.h0 = h0;
@@ -633,7 +720,7 @@ extern "C" int nmpc_mpc_qp(int nb, int Nc, int nx, const double* list_A, const d
     NMPC_REQUIRE(list_A && list_B && list_C && x0 && y_meas && Xs && Us && f0 && Q, "nmpc_mpc_qp: null input");
     if (nb == 0) return 0;
     MpcGeom g;
-    if (mpc_geom(Nc, nx, g)) return 1;
+    if (mpc_geom(Nc, nx, 0, 1, g)) return 1;
     MpcQpArgs a{};
     a.nb = nb; a.nx = nx; a.lA = list_A; a.lB = list_B; a.lC = list_C; a.x0 = x0; a.ymeas = y_meas; a.Xs = Xs; a.Us = Us;
     a.Ge = Ge; a.Fe = Fe; a.Le = Le; a.hv = hv; a.u = u; a.eps = eps; a.xpred = xpred; a.status = status;
@@ -686,23 +773,31 @@ static void prof_end(nmpc_ctrl* c, bool on, hipStream_t s, ProfRec& r) {
 extern "C" int nmpc_ctrl_create(nmpc_ctrl** out, const nmpc_model* m, const nmpc_ctrl_config* cfg) {
     NMPC_REQUIRE(out && m && cfg, "nmpc_ctrl_create: null argument");
     NMPC_REQUIRE(m->d.nu == 1 && m->d.ny == 1, "nmpc_ctrl_create: closed loop needs nu = ny = 1 (as the reference)");
-    NMPC_REQUIRE(m->d.enc && m->d.n_enc_in <= MAX_HIST, "nmpc_ctrl_create: model has no observer net");
+    const int mode = cfg->mode;
+    NMPC_REQUIRE(mode == 0 || mode == 1, "nmpc_ctrl_create: mode %d unknown (0 output feedback, 1 state feedback)", mode);
+    NMPC_REQUIRE(mode == 1 || (m->d.enc && m->d.n_enc_in <= MAX_HIST), "nmpc_ctrl_create: model has no observer net");
+    NMPC_REQUIRE(mode == 0 || m->d.nx == 2, "nmpc_ctrl_create: state feedback drives the two-state disc plant (nx = 2)");
     NMPC_REQUIRE(cfg->Nc * m->d.nx <= 128, "nmpc_ctrl_create: Nc*nx=%d exceeds 128", cfg->Nc * m->d.nx);
     NMPC_REQUIRE(cfg->batch >= 1 && cfg->max_iterations >= 1 && cfg->max_iterations <= 64 && cfg->n_sim >= 1,
                  "nmpc_ctrl_create: bad batch/max_iterations/n_sim");
     NMPC_REQUIRE(cfg->n_nodes >= 1 && cfg->n_nodes <= NMPC_MAX_NODES, "nmpc_ctrl_create: bad node count");
     nmpc_ctrl* c = new nmpc_ctrl();
-    if (mpc_geom(cfg->Nc, m->d.nx, c->g)) { delete c; return 1; }
+    const int slack = (mode == 1 && cfg->hard) ? 0 : 1;
+    if (mpc_geom(cfg->Nc, m->d.nx, mode, slack, c->g)) { delete c; return 1; }
     c->m = m->d;
     NMPC_HIP_CHECK(hipGetDevice(&c->device));
     CtrlDev& d = c->d;
     std::memset(&d, 0, sizeof(d));
     const int B = cfg->batch, Nc = cfg->Nc, nx = m->d.nx;
     d.B = B; d.Nc = Nc; d.nx = nx; d.maxit = cfg->max_iterations; d.n_sim = cfg->n_sim;
-    d.n_enc_in = m->d.n_enc_in;
+    d.n_enc_in = mode ? 1 : m->d.n_enc_in;
     d.na = (d.n_enc_in - 1) / 2; d.nyh = d.n_enc_in - d.na;        // nb inputs, na+1 outputs (na_right = 1)
     d.tol = cfg->tol;
     fill_const(d.c, Nc, nx, cfg->Q, cfg->R, cfg->rho, cfg->u_min, cfg->u_max, cfg->y_min, cfg->y_max, m->d.f0, m->d.h0[0]);
+    if (mode == 1) {   // the state-feedback controllers drop the model offset (rhs_c, NMPC.py:387,520)
+        d.c.mode = 1; d.c.slack = slack;
+        for (int r = 0; r < 4; ++r) { d.c.f0[r] = 0.0; d.c.xmin[r] = cfg->x_min[r]; d.c.xmax[r] = cfg->x_max[r]; d.x0v[r] = cfg->x_norm0[r]; d.xstdv[r] = r < nx ? cfg->x_normstd[r] : 1.0; }
+    }
     d.u0 = cfg->u0; d.ustd = cfg->ustd; d.y0 = cfg->y0; d.ystd = cfg->ystd; d.dt = cfg->dt;
     for (int i = 0; i < 6; ++i) d.plant[i] = cfg->plant[i];
     d.enc = m->d.enc; d.hplain = m->d.hplain;
@@ -718,8 +813,8 @@ extern "C" int nmpc_ctrl_create(nmpc_ctrl** out, const nmpc_model* m, const nmpc
     int rc = 0;
     rc |= alloc((void**)&d.x0n, sb * nx * 8); rc |= alloc((void**)&d.xpred, sb * Nc * nx * 8);
     rc |= alloc((void**)&d.uplan, sb * Nc * 8); rc |= alloc((void**)&d.ymeas, sb * 8);
-    rc |= alloc((void**)&d.xp, sb * 2 * 8); rc |= alloc((void**)&d.uhist, sb * d.na * 8);
-    rc |= alloc((void**)&d.yhist, sb * d.nyh * 8); rc |= alloc((void**)&d.eps, sb * 8);
+    rc |= alloc((void**)&d.xp, sb * 2 * 8); rc |= alloc((void**)&d.uhist, sb * (d.na > 0 ? d.na : 1) * 8);
+    rc |= alloc((void**)&d.yhist, sb * (d.nyh > 0 ? d.nyh : 1) * 8); rc |= alloc((void**)&d.eps, sb * 8);
     rc |= alloc((void**)&d.cnt, sb * 4); rc |= alloc((void**)&d.act, sb * (d.maxit + 1) * 4);
     rc |= alloc((void**)&d.nact, (size_t)(d.maxit + 2) * MAX_SLICES * 4); rc |= alloc((void**)&d.qp_fail, 8); rc |= alloc((void**)&d.qp_stat, sb * 8);
     rc |= alloc((void**)&d.xs32, sb * Nc * nx * 4); rc |= alloc((void**)&d.us32, sb * Nc * 4);
@@ -808,7 +903,7 @@ extern "C" int nmpc_ctrl_run(nmpc_ctrl* c, int k0, int nsteps, const double* Xs,
         const CtrlDev& d = sl.d;
         const size_t o = (size_t)sl.b0;
         RunPtrs rp{};
-        rp.Xs = Xs + o * ntot * nx; rp.Us = Us + o * ntot; rp.noise = noise ? noise + o : nullptr; rp.noise_ld = c->d.B;
+        rp.Xs = Xs + o * ntot * nx; rp.Us = Us + o * ntot; rp.noise = noise ? noise + o * (c->d.c.mode ? nx : 1) : nullptr; rp.noise_ld = c->d.B;
         rp.x_log = x_log ? x_log + o * (ns + 1) * nx : nullptr; rp.u_log = u_log ? u_log + o * ns : nullptr;
         rp.e_log = e_log ? e_log + o * ns : nullptr; rp.y_log = y_log ? y_log + o * (ns + 1) : nullptr;
         rp.y_est_log = y_est_log ? y_est_log + o * (ns + 1) : nullptr;
@@ -827,7 +922,8 @@ extern "C" int nmpc_ctrl_run(nmpc_ctrl* c, int k0, int nsteps, const double* Xs,
             const RunPtrs& rp = sl_rp[i];
             for (int it = 0; it < d.maxit; ++it) {
                 EmbedArgs a{};
-                a.x = d.xs32; a.u = d.us32; a.xc = d.xc32; a.A = d.A32; a.B = d.B32; a.C = d.C32;
+                a.x = d.xs32; a.u = d.us32; a.A = d.A32; a.B = d.B32;
+                if (d.c.mode == 0) { a.xc = d.xc32; a.C = d.C32; }
                 a.npts = d.B * d.Nc; a.group = d.Nc;
                 if (it > 0) { a.count_dev = d.nact + it; a.act = d.act + (size_t)it * d.B; }
                 ProfRec pr;
@@ -841,7 +937,8 @@ extern "C" int nmpc_ctrl_run(nmpc_ctrl* c, int k0, int nsteps, const double* Xs,
             ProfRec pr;
             const bool on = prof_begin(c, 2, k, s, pr);
             const int threads = 64 * PLANT_WAVES, grid = (d.B + PLANT_WAVES - 1) / PLANT_WAVES;
-            if (d.nx == 2) hipLaunchKernelGGL((plant_kernel<2>), dim3(grid), dim3(threads), 0, s, d, rp, k);
+            if (d.c.mode == 1) hipLaunchKernelGGL((plant_state_kernel<2>), dim3((d.B + 127) / 128), dim3(128), 0, s, d, rp, k);
+            else if (d.nx == 2) hipLaunchKernelGGL((plant_kernel<2>), dim3(grid), dim3(threads), 0, s, d, rp, k);
             else if (d.nx == 3) hipLaunchKernelGGL((plant_kernel<3>), dim3(grid), dim3(threads), 0, s, d, rp, k);
             else { set_error("nmpc_ctrl_run: nx=%d unsupported", d.nx); return 1; }
             NMPC_HIP_CHECK(hipGetLastError());

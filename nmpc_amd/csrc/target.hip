@@ -22,6 +22,9 @@ struct TargetArgs {
     int nb, nsamp, max_lpv;
     double tol, umin, umax, ymin, ymax, h0;
     double f0[4];
+    // state-constrained variant (mpcUtil.py:167-239 getXsUs): fixed output row Cfix, box on xs itself
+    int state;
+    double Cfix[4], xmin[4], xmax[4];
     const double* yref;
     double *Xs, *Us, *Es;
     int *iters, *status;
@@ -48,7 +51,7 @@ __global__ void target_kernel(TargetArgs a, int j, int i) {
     }
     double Cs[NX];
 #pragma unroll
-    for (int c = 0; c < NX; ++c) { Cs[c] = (double)a.C32[(size_t)b * NX + c]; M[NX][c] = Cs[c]; }
+    for (int c = 0; c < NX; ++c) { Cs[c] = a.state ? a.Cfix[c] : (double)a.C32[(size_t)b * NX + c]; M[NX][c] = Cs[c]; }
     M[NX][NX] = 0.0;
     M[NX][N] = a.yref[(size_t)b * a.nsamp + j] - a.h0;
     bool singular = false;
@@ -89,7 +92,13 @@ __global__ void target_kernel(TargetArgs a, int j, int i) {
         dx += d * d;
     }
     const double du = fabs(usn - a.us[b]);
-    double v = fmax(fmax(-usn + a.umin, usn - a.umax), fmax(-cy + a.ymin, cy - a.ymax));
+    double v = fmax(-usn + a.umin, usn - a.umax);
+    if (a.state) {
+#pragma unroll
+        for (int c = 0; c < NX; ++c) v = fmax(v, fmax(-z[c] + a.xmin[c], z[c] - a.xmax[c]));
+    } else {
+        v = fmax(v, fmax(-cy + a.ymin, cy - a.ymax));
+    }
     const double e = v > 0.0 ? v : 0.0;
 #pragma unroll
     for (int c = 0; c < NX; ++c) {
@@ -113,24 +122,13 @@ __global__ void target_kernel(TargetArgs a, int j, int i) {
 
 using namespace nmpc;
 
-extern "C" int nmpc_target_select(const nmpc_model* m, int nb, int nsamp, const double* y_ref_n, double u_min,
-                                  double u_max, double y_min, double y_max, const float* lam, const float* w,
-                                  int n_nodes, int max_lpv, double tol, double* Xs, double* Us, double* Es,
-                                  int* iters, int* status, void* stream) {
-    NMPC_REQUIRE(m && y_ref_n && lam && w && Xs && Us && Es && status, "nmpc_target_select: null argument");
-    NMPC_REQUIRE(m->d.nu == 1 && m->d.ny == 1, "nmpc_target_select: needs nu = ny = 1 (as the reference)");
-    NMPC_REQUIRE(nb >= 1 && nsamp >= 1 && max_lpv >= 1 && max_lpv <= 1024, "nmpc_target_select: bad sizes");
-    NMPC_REQUIRE(n_nodes >= 1 && n_nodes <= NMPC_MAX_NODES, "nmpc_target_select: bad node count");
+static int target_run(const nmpc_model* m, TargetArgs a, const float* lam, const float* w, int n_nodes, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    const int nx = m->d.nx;
+    const int nx = m->d.nx, nb = a.nb, nsamp = a.nsamp, max_lpv = a.max_lpv;
+    int* status = a.status;
     NodeTable nt;
     nt.n = n_nodes;
     for (int i = 0; i < NMPC_MAX_NODES; ++i) { nt.lam[i] = i < n_nodes ? lam[i] : 0.f; nt.w[i] = i < n_nodes ? w[i] : 0.f; }
-    TargetArgs a{};
-    a.nb = nb; a.nsamp = nsamp; a.max_lpv = max_lpv; a.tol = tol;
-    a.umin = u_min; a.umax = u_max; a.ymin = y_min; a.ymax = y_max; a.h0 = m->d.h0[0];
-    for (int r = 0; r < nx; ++r) a.f0[r] = m->d.f0[r];
-    a.yref = y_ref_n; a.Xs = Xs; a.Us = Us; a.Es = Es; a.iters = iters; a.status = status;
     // one slab: xs, us (fp64) | xs32 us32 A32 B32 C32 (fp32) | act[2][nb], counts[max_lpv+1] (int)
     const size_t nB = (size_t)nb;
     const size_t bytes = nB * (nx + 1) * 8 + nB * (size_t)(nx + 1 + nx * nx + nx + nx) * 4 + (2 * nB + max_lpv + 2) * 4;
@@ -150,7 +148,8 @@ extern "C" int nmpc_target_select(const nmpc_model* m, int nb, int nsamp, const 
         if (hipMemsetAsync(a.counts, 0, (max_lpv + 1) * 4, s) != hipSuccess) { rc = 1; break; }
         for (int i = 0; i < max_lpv && !rc; ++i) {
             EmbedArgs ea{};
-            ea.x = a.xs32; ea.u = a.us32; ea.xc = a.xs32; ea.A = a.A32; ea.B = a.B32; ea.C = a.C32;
+            ea.x = a.xs32; ea.u = a.us32; ea.A = a.A32; ea.B = a.B32;
+            if (!a.state) { ea.xc = a.xs32; ea.C = a.C32; }
             ea.npts = nb; ea.group = 1;
             if (i > 0) { ea.count_dev = a.counts + i; ea.act = a.act + (size_t)(i & 1) * nb; }
             rc = embed_launch(m->d, ea, nt, s);
@@ -166,4 +165,41 @@ extern "C" int nmpc_target_select(const nmpc_model* m, int nb, int nsamp, const 
     if (rc) return 1;
     NMPC_REQUIRE(e1 == hipSuccess && e2 == hipSuccess, "nmpc_target_select: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
     return 0;
+}
+
+extern "C" int nmpc_target_select(const nmpc_model* m, int nb, int nsamp, const double* y_ref_n, double u_min,
+                                  double u_max, double y_min, double y_max, const float* lam, const float* w,
+                                  int n_nodes, int max_lpv, double tol, double* Xs, double* Us, double* Es,
+                                  int* iters, int* status, void* stream) {
+    NMPC_REQUIRE(m && y_ref_n && lam && w && Xs && Us && Es && status, "nmpc_target_select: null argument");
+    NMPC_REQUIRE(m->d.nu == 1 && m->d.ny == 1, "nmpc_target_select: needs nu = ny = 1 (as the reference)");
+    NMPC_REQUIRE(nb >= 1 && nsamp >= 1 && max_lpv >= 1 && max_lpv <= 1024, "nmpc_target_select: bad sizes");
+    NMPC_REQUIRE(n_nodes >= 1 && n_nodes <= NMPC_MAX_NODES, "nmpc_target_select: bad node count");
+    TargetArgs a{};
+    a.nb = nb; a.nsamp = nsamp; a.max_lpv = max_lpv; a.tol = tol;
+    a.umin = u_min; a.umax = u_max; a.ymin = y_min; a.ymax = y_max; a.h0 = m->d.h0[0];
+    for (int r = 0; r < m->d.nx; ++r) a.f0[r] = m->d.f0[r];
+    a.yref = y_ref_n; a.Xs = Xs; a.Us = Us; a.Es = Es; a.iters = iters; a.status = status;
+    return target_run(m, a, lam, w, n_nodes, stream);
+}
+
+extern "C" int nmpc_target_select_state(const nmpc_model* m, int nb, int nsamp, const double* y_ref_n, double u_min,
+                                        double u_max, const double* x_min, const double* x_max, const double* C,
+                                        const double* f0, double h0, const float* lam, const float* w, int n_nodes,
+                                        int max_lpv, double tol, double* Xs, double* Us, double* Es, int* iters,
+                                        int* status, void* stream) {
+    NMPC_REQUIRE(m && y_ref_n && x_min && x_max && C && lam && w && Xs && Us && Es && status,
+                 "nmpc_target_select_state: null argument");
+    NMPC_REQUIRE(m->d.nu == 1, "nmpc_target_select_state: needs nu = 1 and one output row (as the reference)");
+    NMPC_REQUIRE(nb >= 1 && nsamp >= 1 && max_lpv >= 1 && max_lpv <= 1024, "nmpc_target_select_state: bad sizes");
+    NMPC_REQUIRE(n_nodes >= 1 && n_nodes <= NMPC_MAX_NODES, "nmpc_target_select_state: bad node count");
+    TargetArgs a{};
+    a.nb = nb; a.nsamp = nsamp; a.max_lpv = max_lpv; a.tol = tol;
+    a.umin = u_min; a.umax = u_max; a.h0 = h0; a.state = 1;
+    for (int r = 0; r < m->d.nx; ++r) {
+        a.f0[r] = f0 ? f0[r] : m->d.f0[r];
+        a.Cfix[r] = C[r]; a.xmin[r] = x_min[r]; a.xmax[r] = x_max[r];
+    }
+    a.yref = y_ref_n; a.Xs = Xs; a.Us = Us; a.Es = Es; a.iters = iters; a.status = status;
+    return target_run(m, a, lam, w, n_nodes, stream);
 }

@@ -16,7 +16,13 @@ class Norm:
     """deepSI System_data_norm: u_norm = (u - u0)/ustd, y_norm = (y - y0)/ystd."""
 
     def __init__(self, u0=0.0, ustd=1.0, y0=0.0, ystd=1.0):
-        self.u0, self.ustd, self.y0, self.ystd = float(u0), float(ustd), float(y0), float(ystd)
+        """y0 / ystd may be vectors (a full-state model's state normalisation, NMPC.py:524-525): they
+        are kept as y0v / ystdv and the scalar fields hold their first entries."""
+        self.u0, self.ustd = float(u0), float(ustd)
+        y0a, ysa = np.atleast_1d(np.asarray(y0, np.float64)), np.atleast_1d(np.asarray(ystd, np.float64))
+        self.y0, self.ystd = float(y0a[0]), float(ysa[0])
+        if y0a.size > 1 or ysa.size > 1:
+            self.y0v, self.ystdv = y0a.copy(), ysa.copy()
 
 
 class Encoder:

@@ -38,6 +38,13 @@ class OutputUnbalancedDisc:
         return [self.g, self.J, self.Km, self.I, self.M, self.tau]
 
 
+class NoisyUnbalancedDisc(OutputUnbalancedDisc):
+    """Full-state measurement x + N(0, sigma_n[r]) per component (Systems.py:58-77)."""
+
+    def __init__(self, dt=0.025, sigma_n=(0, 0), seed=0):
+        super().__init__(dt, sigma_n, seed)
+
+
 def mpc_qp(list_A, list_B, list_C, x0, y_meas, Xs, Us, f0, h0, Q, R, rho, u_min, u_max, y_min, y_max, Nc, nx,
            want_matrices=False):
     """One condensed QP of the output-constrained controller (NMPC_test.py:206-238), batched.
@@ -71,7 +78,9 @@ class Controller:
     """Batch of closed-loop controllers resident on the GPU (nmpc_ctrl of the C ABI)."""
 
     def __init__(self, encoder, system, batch, Nc, Nsim, max_iterations, Q, R, u_min_n, u_max_n, y_min_n, y_max_n,
-                 nodes, weights, tol=1e-1, rho=1000.0):
+                 nodes, weights, tol=1e-1, rho=1000.0, state_feedback=None):
+        """state_feedback: None for the output-feedback controller, or a dict(x_min, x_max [nx] normalised
+        state bounds, y0, ystd [nx] state normalisation, hard=bool) for the state-feedback controllers."""
         cfg = _lib.CtrlConfig()
         cfg.batch, cfg.Nc, cfg.max_iterations, cfg.n_sim = int(batch), int(Nc), int(max_iterations), int(Nsim)
         cfg.tol, cfg.rho = float(tol), float(rho)
@@ -88,6 +97,14 @@ class Controller:
         cfg.n_nodes = len(nodes)
         for i in range(len(nodes)):
             cfg.lam[i] = float(nodes[i]); cfg.w[i] = float(weights[i])
+        self.state_feedback = state_feedback is not None
+        if state_feedback is not None:
+            cfg.mode, cfg.hard = 1, int(bool(state_feedback.get("hard", False)))
+            for i in range(encoder.nx):
+                cfg.x_min[i] = float(np.asarray(state_feedback["x_min"]).reshape(-1)[i])
+                cfg.x_max[i] = float(np.asarray(state_feedback["x_max"]).reshape(-1)[i])
+                cfg.x_norm0[i] = float(np.asarray(state_feedback["y0"]).reshape(-1)[i])
+                cfg.x_normstd[i] = float(np.asarray(state_feedback["ystd"]).reshape(-1)[i])
         self.encoder, self.cfg = encoder, cfg
         self.B, self.Nc, self.Nsim, self.nx = int(batch), int(Nc), int(Nsim), encoder.nx
         h = ctypes.c_void_p()
@@ -119,11 +136,12 @@ class Controller:
         check(rc, "nmpc_ctrl_reset")
 
     def set_targets(self, Xs, Us, noise=None):
-        """Xs [B, Nsim+Nc, nx], Us [B, Nsim+Nc], noise [Nsim, B] (device fp64)."""
+        """Xs [B, Nsim+Nc, nx], Us [B, Nsim+Nc], noise [Nsim, B] (state feedback: [Nsim, B, nx]), device fp64."""
         dev = self.encoder.device
         self.Xs = _f64(Xs, dev).reshape(self.B, self.Nsim + self.Nc, self.nx)
         self.Us = _f64(Us, dev).reshape(self.B, self.Nsim + self.Nc)
-        self.noise = None if noise is None else _f64(noise, dev).reshape(self.Nsim, self.B)
+        shape = (self.Nsim, self.B, self.nx) if self.state_feedback else (self.Nsim, self.B)
+        self.noise = None if noise is None else _f64(noise, dev).reshape(shape)
 
     def run(self, k0, nsteps):
         L = self.logs
@@ -249,3 +267,118 @@ def output_NMPC_linear(system, encoder, u_min, u_max, y_min, y_max, x0, Q, R, dt
     if return_controller:
         return tuple(out), ctrl
     return tuple(out)
+
+
+def _state_loop(system, encoder, x_min, x_max, u_min, u_max, x0, Q, R, dt, dlam, stages, x_reference_list, Nc, Nsim,
+                max_iterations, tol, rho, hard, noise, C, targets):
+    """Shared body of par_NMPC_linear / NMPC_linear: returns (x_log, u_log, e_log, comp_t_log, t, runtime,
+    lpv_counter, reference_list_normalized, per-step kernel ms [Nsim, 3], controller)."""
+    from .target import getXsUs, GetABC
+    _lib.require_gpu()
+    dev = encoder.device
+    nx, nu = encoder.nx, encoder.nu
+    nm = encoder.norm
+    y0 = np.broadcast_to(np.asarray(nm.y0v if hasattr(nm, "y0v") else nm.y0, np.float64), (nx,)).copy()
+    ystd = np.broadcast_to(np.asarray(nm.ystdv if hasattr(nm, "ystdv") else nm.ystd, np.float64), (nx,)).copy()
+    lam, w = quad_nodes("simpson", stages, dlam)                       # lpv_int, NMPC.py:400,533
+    x0 = np.asarray(x0, np.float64).reshape(-1)
+    xmax_n = (np.asarray(x_max, np.float64) - y0) / ystd; xmin_n = (np.asarray(x_min, np.float64) - y0) / ystd
+    umin_n = (float(u_min) - nm.u0) / nm.ustd; umax_n = (float(u_max) - nm.u0) / nm.ustd
+    refn = None
+    if x_reference_list is not None:
+        ref = torch.as_tensor(np.asarray(x_reference_list, np.float64))
+        single = ref.dim() == 2
+        if single:
+            ref = ref[None]
+        B = ref.shape[0]
+        assert ref.shape[1] == nx and ref.shape[2] >= Nsim + Nc, "reference must be [B, nx, >= Nsim+Nc]"
+        refn = (ref - torch.as_tensor(y0)[None, :, None]) / torch.as_tensor(ystd)[None, :, None]     # NMPC.py:524
+        if targets is None:
+            Xs, Us, _ = getXsUs(refn[:, 1, :Nsim + Nc].to(dev), nx, nu, 1, Nsim + Nc, umin_n, umax_n, xmin_n, xmax_n,
+                                GetABC(encoder, lam, w), None, np.asarray(C, np.float64), None, 0.0)
+        else:
+            Xs, Us = (_f64(t, dev) for t in targets)
+            Xs = Xs.reshape(B, nx, -1)[:, :, :Nsim + Nc]; Us = Us.reshape(B, nu, -1)[:, :, :Nsim + Nc]
+        u0n = (0 - nm.u0) / nm.ustd                                    # NMPC.py:526-527
+    else:
+        x0 = x0.reshape(-1, nx)
+        B, single = x0.shape[0], x0.shape[0] == 1
+        Xs = torch.zeros(B, nx, Nsim + Nc, dtype=torch.float64, device=dev)
+        Us = torch.zeros(B, nu, Nsim + Nc, dtype=torch.float64, device=dev)
+        u0n = 0.0                                                      # NMPC.py:427
+    x0b = np.broadcast_to(x0.reshape(-1, nx), (B, nx))
+    if not np.all(x0b == x0b[0]):
+        raise _lib.NmpcError("state-feedback loops start every controller of a batch from the same x0")
+    ctrl = Controller(encoder, system, B, Nc, Nsim, max_iterations, Q, R, umin_n, umax_n, 0.0, 0.0, lam, w, tol=tol,
+                      rho=rho, state_feedback=dict(x_min=xmin_n, x_max=xmax_n, y0=y0, ystd=ystd, hard=hard))
+    if noise is None and any(float(sg) > 0 for sg in system.sigma_n):
+        gen = torch.Generator(device="cpu"); gen.manual_seed(system.seed)
+        noise = torch.randn(Nsim, B, nx, generator=gen, dtype=torch.float64) * torch.as_tensor(
+            np.asarray(system.sigma_n, np.float64)[:nx])
+    ctrl.set_targets(Xs.transpose(1, 2).contiguous(), Us[:, 0, :].contiguous(), noise)
+    ctrl.reset((x0b[0] - y0) / ystd, u0n, x0b[0])
+    comp_t_log = np.zeros(Nsim)
+    torch.cuda.synchronize(dev)
+    start = time.time()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(Nsim + 1)]
+    ctrl.profile(1)
+    ev[0].record()
+    for k in range(Nsim):
+        ctrl.run(k, 1)
+        ev[k + 1].record()
+    torch.cuda.synchronize(dev)
+    runtime = time.time() - start
+    for k in range(Nsim):
+        comp_t_log[k] = ev[k].elapsed_time(ev[k + 1]) * 1e-3
+    kms = ctrl.profile_read_steps(0, Nsim)
+    ctrl.profile(0)
+    nfail = ctrl.qp_failures()
+    if nfail:
+        raise _lib.NmpcError("state-feedback NMPC: %d QP solves failed (infeasible hard constraints?)" % nfail)
+    L = ctrl.logs
+    x_log = L["x_log"].clone(); x_log[:, 0, :] = torch.as_tensor(np.array(x0b[0]), device=dev)
+    x_log = x_log.reshape(B, (Nsim + 1) * nx)
+    e_log = torch.zeros(B, nx, Nsim, dtype=torch.float64, device=dev); e_log[:, 0, :] = L["e_log"]
+    out = [x_log, L["u_log"], e_log, comp_t_log, np.arange(Nsim) * dt, runtime, L["lpv_counter"], refn]
+    if single:
+        out = [o[0] if torch.is_tensor(o) else o for o in out]
+    return out, kms, ctrl
+
+
+def par_NMPC_linear(system, encoder, x_min, x_max, u_min, u_max, x0, u_ref, Q, R, dt, dlam, stages, x_reference_list,
+                    Nc=5, Nsim=30, max_iterations=1, *, tol=1e-5, rho=10000.0, noise=None, C=(0.0, 1.0), targets=None,
+                    return_controller=False):
+    """State-feedback LPV-NMPC tracking the targets of getXsUs (NMPC.py:507-650), batched:
+    x_reference_list [B, nx, >= Nsim+Nc] (or [nx, ...] for one controller), physical units; row 1 is the
+    tracked output (NMPC.py:539-540).  Soft state/input box through one slack (weight 10000).  u_ref is
+    accepted and unused, as in the reference.  Returns the reference's 9-tuple (x_log, u_log, e_log,
+    comp_t_log, t, runtime, lpv_counter, reference_list_normalized, components_time)."""
+    out, kms, ctrl = _state_loop(system, encoder, x_min, x_max, u_min, u_max, x0, Q, R, dt, dlam, stages,
+                                 x_reference_list, Nc, Nsim, max_iterations, tol, rho, False, noise, C, targets)
+    components_time = np.zeros((4, Nsim * max_iterations))              # NMPC.py:560; column k*max_iterations = step k
+    components_time[0, ::max_iterations] = kms[:, 0] * 1e-3
+    components_time[1, ::max_iterations] = kms[:, 1] * 1e-3
+    components_time[3, ::max_iterations] = kms[:, 2] * 1e-3
+    components_time[2, ::max_iterations] = np.maximum(out[3] - kms.sum(1) * 1e-3, 0.0)
+    res = tuple(out) + (components_time,)
+    return (res, ctrl) if return_controller else res
+
+
+def NMPC_linear(system, encoder, x_min, x_max, u_min, u_max, x0, u_ref, Q, R, dt, dlam, stages, x_reference_list=None,
+                Nc=5, Nsim=30, max_iterations=5, *, tol=1e-7, noise=None, return_controller=False):
+    """State-feedback LPV-NMPC regulating to the origin with hard state/input constraints
+    (NMPC.py:374-505; its QP goes to quadprog, the dual active-set method this library implements;
+    at most 5 passes, stop 1e-7).  x0 [nx] or [B, nx] (all rows equal).  Returns the reference's 9-tuple
+    (x_log, u_log, e_log, comp_t_log, t, runtime, lpv_counter, reference_list_normalized,
+    components_total_time[4])."""
+    out, kms, ctrl = _state_loop(system, encoder, x_min, x_max, u_min, u_max, x0, Q, R, dt, dlam, stages, None, Nc,
+                                 Nsim, max_iterations, tol, 1.0, True, noise, (0.0, 1.0), None)
+    if x_reference_list is not None:                                    # NMPC.py:391 (returned, not tracked)
+        nm = encoder.norm
+        y0 = np.asarray(nm.y0v if hasattr(nm, "y0v") else nm.y0, np.float64)
+        ystd = np.asarray(nm.ystdv if hasattr(nm, "ystdv") else nm.ystd, np.float64)
+        out[7] = ((np.asarray(x_reference_list, np.float64).T - y0) / ystd).T
+    tot = kms.sum(0) * 1e-3
+    components_total_time = np.array([tot[0], tot[1], max(out[3].sum() - tot.sum(), 0.0), tot[2]])   # NMPC.py:423
+    res = tuple(out) + (components_total_time,)
+    return (res, ctrl) if return_controller else res

@@ -55,3 +55,49 @@ def getXsUs_Cs(y_reference_list_normalize, nx, nu, ny, Nsim, u_min, u_max, y_min
     if return_iters:
         return out + (iters[0] if single else iters,)
     return out
+
+
+def getXsUs(y_reference_list_normalize, nx, nu, ny, Nsim, u_min, u_max, x_min, x_max, get_A, get_B=None, C=None,
+            f0=None, h0=0.0, *, max_lpv=10, tol=1e-5, return_iters=False):
+    """State-constrained target selector with the reference's signature (mpcUtil.py:167-239).
+    get_A: a GetABC handle (or the model with (lam, w) in get_B).  C: output row(s) [ny, nx] (ny = 1),
+    f0: equality offset (None: the model's f(0,0), what NMPC.py:542 passes), h0: output offset.
+    Iterates until xs, us stop changing (the reference's loop compares against a view of the buffer
+    the next solve overwrites, mpcUtil.py:226-233, and so stops after one repeat).
+    Returns (Xs [B, nx, Nsim], Us [B, nu, Nsim], Es [B, 1, Nsim])."""
+    if not isinstance(get_A, GetABC):
+        get_A = GetABC(get_A, *get_B)
+    model = get_A.model
+    assert (nx, nu) == (model.nx, model.nu) and ny == 1
+    dev = model.device
+    yr = _f64(y_reference_list_normalize, dev)
+    single = yr.dim() == 1
+    if single:
+        yr = yr[None]
+    yr = yr[:, :Nsim].contiguous()
+    B = yr.shape[0]
+    Xs = torch.empty(B, Nsim, nx, dtype=torch.float64, device=dev)
+    Us = torch.empty(B, Nsim, dtype=torch.float64, device=dev)
+    Es = torch.empty(B, Nsim, dtype=torch.float64, device=dev)
+    iters = torch.zeros(B, Nsim, dtype=torch.int32, device=dev)
+    status = torch.zeros(B, dtype=torch.int32, device=dev)
+    vec = lambda v: np.ascontiguousarray(np.asarray(v, np.float64).reshape(-1))
+    xmin, xmax, Cv = vec(x_min), vec(x_max), vec(C)
+    f0v = None if f0 is None else vec(f0)
+    dp = lambda a: None if a is None else a.ctypes.data_as(_lib.c_double_p)
+    with torch.cuda.device(dev):
+        rc = lib().nmpc_target_select_state(model.handle, B, Nsim, ptr(yr), float(u_min), float(u_max), dp(xmin), dp(xmax),
+                                            dp(Cv), dp(f0v), float(np.asarray(h0).reshape(-1)[0]),
+                                            get_A.lam.ctypes.data_as(_lib.c_float_p),
+                                            get_A.w.ctypes.data_as(_lib.c_float_p), get_A.lam.size, int(max_lpv),
+                                            float(tol), ptr(Xs), ptr(Us), ptr(Es), ptr(iters), ptr(status),
+                                            current_stream())
+    check(rc, "nmpc_target_select_state")
+    if int(status.sum()):
+        raise _lib.NmpcError("getXsUs: singular steady-state system for %d controllers" % int((status != 0).sum()))
+    out = (Xs.transpose(1, 2).contiguous(), Us[:, None, :].contiguous(), Es[:, None, :].contiguous())
+    if single:
+        out = tuple(o[0] for o in out)
+    if return_iters:
+        return out + (iters[0] if single else iters,)
+    return out

@@ -158,3 +158,132 @@ def output_nmpc_linear(model, u_min, u_max, y_min, y_max, x0, Q, R, dt, stages, 
     return dict(x_log=x_log, u_log=u_log, e_log=e_log, lpv_counter=lpv_counter, y_log=y_log,
                 y_est_log=y_est_log, Xs=Xs_all, Us=Us_all, plan_log=plan_log, abc_first=abc_first,
                 y_ref_n=y_ref_n)
+
+
+# ------------------------------------------------------------------------------------------
+# State-feedback variants (NMPC.py:374-650): the full state is measured, box constraints act on
+# the predicted states through getDEMc, no observer and no output map.  The model offset is
+# removed (rhs_c = rhs - f(0,0), NMPC.py:387,520), so predictions are Phi x0 + Gamma u.
+#
+# Departures from the code as written, all in favour of what the later output-feedback controller
+# (NMPC_test.py) does for the same step:
+#   - input targets follow the step, Us = us[k : k+Nc]  (NMPC.py:580 always takes the first Nc);
+#   - linear cost term 2 (Gamma' Omega (Phi x0 - Xs) - Psi Us)  (NMPC.py:591 adds Psi' Us);
+#   - the input warm start shifts by nu  (NMPC.py:495,640 shift it by nx);
+#   - getXsUs iterates until xs, us stop changing (mpcUtil.py:226-233 compares xs with a view of the
+#     buffer the next solve overwrites, which ends the loop after one repeat).
+def target_selector_state(model, y_ref_norm, Nsim, u_min, u_max, x_min, x_max, C, nodes, weights,
+                          f0=None, h0=0.0, max_lpv=10, tol=1e-5, lam=100.0):
+    """mpcUtil.py:167-239 getXsUs: steady states with box constraints on (xs, us), fixed output
+    matrix C; returns Xs [nx, Nsim], Us [nu, Nsim], Es [1, Nsim], iteration counts."""
+    nx, nu, ne = model.nx, model.nu, 1
+    C = np.atleast_2d(np.asarray(C, float)); ny = C.shape[0]
+    Q = np.eye(ny); R = np.eye(nu)
+    Mi = np.vstack([np.zeros((nu, nx)), np.zeros((nu, nx)), -np.eye(nx), np.eye(nx)])
+    Ei = np.vstack([-np.eye(nu), np.eye(nu), np.zeros((nx, nu)), np.zeros((nx, nu))])
+    hvec = np.concatenate([[-u_min, u_max], -np.asarray(x_min, float), np.asarray(x_max, float)])
+    f0 = np.asarray(model.f0 if f0 is None else f0, float).reshape(nx)
+    h0 = np.atleast_1d(np.asarray(h0, float))
+    nv = nx + nu + ne
+    T = np.zeros((2 * (nx + nu), nv)); T[:, :nx] = Mi; T[:, nx:nx + nu] = Ei; T[:, nx + nu:] = -1.0
+    P = np.zeros((nv, nv)); P[:nx, :nx] = C.T @ Q @ C; P[nx:nx + nu, nx:nx + nu] = R; P[nx + nu:, nx + nu:] = lam
+    q = np.zeros(nv)
+    Aeq = np.zeros((nx + ny, nv)); Aeq[nx:, :nx] = C
+    beq = np.zeros(nx + ny); beq[:nx] = f0
+    xs = np.zeros(nx); us = np.zeros(nu)
+    Xs = np.zeros((nx, Nsim)); Us = np.zeros((nu, Nsim)); Es = np.zeros((ne, Nsim)); iters = np.zeros(Nsim, int)
+    for j in range(Nsim):
+        beq[nx:] = y_ref_norm[j] - h0
+        q[:nx] = C.T @ Q @ (h0 - y_ref_norm[j])
+        for i in range(max_lpv):
+            As, Bs, _ = lpv.embed(model, xs, us, nodes, weights)
+            Aeq[:nx, :nx] = np.eye(nx) - As
+            Aeq[:nx, nx:nx + nu] = -Bs
+            z = solve_qp(P, q, T, hvec, Aeq, beq)
+            xold, uold = xs, us
+            xs, us, e = z[:nx].copy(), z[nx:nx + nu].copy(), z[nx + nu:].copy()
+            iters[j] = i + 1
+            if np.linalg.norm(xs - xold) <= tol and np.linalg.norm(us - uold) <= tol:
+                break
+        Xs[:, j], Us[:, j], Es[:, j] = xs, us, e
+    return Xs, Us, Es, iters
+
+
+def state_mpc_qp(list_A, list_B, x0, Xs, Us, Psi, Omega, D, E, M, c, Nc, nx, nu, rho):
+    """Condensed QP of the state-feedback controllers (NMPC.py:446-458, 588-604).  rho = None: hard
+    constraints, variables u (NMPC_linear); otherwise one slack with weight rho on every row."""
+    Phi = mpcutil.getPhi(list_A, Nc, nx, nu)
+    Gamma = mpcutil.getGamma(list_A, list_B, Nc, nx, nu)
+    G = 2 * (Psi + Gamma.T @ Omega @ Gamma)
+    F = 2 * (Gamma.T @ Omega @ (Phi @ x0 - Xs) - Psi @ Us)
+    L = M @ Gamma + E
+    hv = c[:, 0] - (D + M @ Phi) @ x0
+    if rho is None:
+        u = solve_qp(G, F, L, hv); eps = 0.0
+        pieces = dict(Ge=G, Fe=F, Le=L, h=hv)
+    else:
+        nvar = Nc * nu + 1
+        Ge = np.zeros((nvar, nvar)); Ge[:-1, :-1] = G; Ge[-1, -1] = rho
+        Fe = np.append(F, 0.0); Le = np.hstack([L, -np.ones((L.shape[0], 1))])
+        ue = solve_qp(Ge, Fe, Le, hv); u, eps = ue[:-1], ue[-1]
+        pieces = dict(Ge=Ge, Fe=Fe, Le=Le, h=hv)
+    return u, eps, Phi @ x0 + Gamma @ u, pieces
+
+
+def state_nmpc_linear(model, x_min, x_max, u_min, u_max, x0, Q, R, dt, dlam, stages, x_reference_list=None,
+                      Nc=5, Nsim=30, max_iterations=1, tol=1e-5, rho=10000.0, noise=None, y0=None, ystd=None,
+                      C=(0.0, 1.0), targets=None):
+    """Closed loop with measured state, single controller.
+    x_reference_list [nx, >= Nsim+Nc] given: par_NMPC_linear (NMPC.py:507-650; tracking of the targets
+    from getXsUs on row 1 of the reference, slack weight rho = 10000, stop 1e-5).
+    x_reference_list None: NMPC_linear (NMPC.py:374-505; regulation to the origin, hard constraints:
+    pass rho=None, stop 1e-7, at most 5 passes there).
+    y0, ystd: state normalisation vectors (norm.y0, norm.ystd of a full-state model); noise [Nsim, nx].
+    Returns a dict of logs."""
+    nx, nu = model.nx, model.nu
+    nodes, weights = lpv.merge_nodes(*lpv.quad_nodes("simpson", stages, dlam))   # lpv_int, NMPC.py:400,533
+    y0 = np.zeros(nx) if y0 is None else np.asarray(y0, float).reshape(nx)
+    ystd = np.ones(nx) if ystd is None else np.asarray(ystd, float).reshape(nx)
+    x0 = np.asarray(x0, float)
+    x0n = (x0 - y0) / ystd
+    xmax_n = (np.asarray(x_max, float) - y0) / ystd; xmin_n = (np.asarray(x_min, float) - y0) / ystd
+    umin_n = (u_min - model.u0) / model.ustd; umax_n = (u_max - model.u0) / model.ustd
+    if x_reference_list is not None:
+        refn = ((np.asarray(x_reference_list, float).T - y0) / ystd).T
+        if targets is None:
+            Xs_all, Us_all, _, _ = target_selector_state(model, refn[1], Nsim + Nc, umin_n, umax_n, xmin_n, xmax_n,
+                                                         np.asarray(C, float), nodes, weights, h0=0.0)
+        else:
+            Xs_all, Us_all = targets
+        u = np.tile((0 - model.u0) / model.ustd, Nc).astype(float)
+    else:
+        Xs_all = np.zeros((nx, Nsim + Nc + 1)); Us_all = np.zeros((nu, Nsim + Nc + 1))
+        u = np.zeros(Nc * nu)
+    Psi = mpcutil.getPsi(Nc, R); Omega = mpcutil.getOmega(Nc, Q)
+    D, E, M, c = mpcutil.getDEMc(xmin_n, xmax_n, umin_n, umax_n, Nc, nx, nu)
+    x = np.tile(x0n, Nc)                     # scheduling states x_0 .. x_{Nc-1}
+    xp = x0.copy()
+    u_log = np.zeros(Nsim); x_log = np.zeros((Nsim + 1, nx)); x_log[0] = x0; e_log = np.zeros(Nsim)
+    lpv_counter = np.zeros(Nsim, int); plan_log = np.zeros((Nsim, Nc))
+    for k in range(Nsim):
+        Xs = Xs_all[:, k + 1:k + Nc + 1].T.reshape(nx * Nc)
+        Us = Us_all[:, k:k + Nc].T.reshape(Nc * nu)
+        while True:
+            A, B, _ = lpv.embed(model, x.reshape(Nc, nx), u.reshape(Nc, nu), nodes, weights)
+            u_old = u.copy()
+            u, eps, xpred, _ = state_mpc_qp(A.reshape(Nc * nx, nx), B.reshape(Nc * nx, nu), x[:nx], Xs, Us, Psi, Omega,
+                                            D, E, M, c, Nc, nx, nu, rho)
+            x[nx:] = xpred[:(Nc - 1) * nx]
+            lpv_counter[k] += 1
+            if lpv_counter[k] >= max_iterations or np.linalg.norm(u - u_old) < tol:
+                break
+        plan_log[k] = u
+        u_den = model.ustd * u[0] + model.u0
+        xp = disc_step(xp, u_den, dt)
+        x_meas = xp + (0.0 if noise is None else noise[k])
+        x0n = (x_meas - y0) / ystd
+        x_log[k + 1] = x_meas; u_log[k] = u_den; e_log[k] = eps
+        x = np.concatenate([x[nx:], xpred[-nx:]])        # x[nx:(Nc+1)nx] of the reference's longer buffer
+        x[:nx] = x0n
+        u = np.concatenate([u[nu:], u[-nu:]])
+    return dict(x_log=x_log, u_log=u_log, e_log=e_log, lpv_counter=lpv_counter, Xs=Xs_all, Us=Us_all, plan_log=plan_log)

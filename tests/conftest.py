@@ -42,3 +42,24 @@ def disc_setup(omodel, Nc=10):
     umin = (-4 - omodel.u0) / omodel.ustd
     umax = (4 - omodel.u0) / omodel.ustd
     return dict(ymin=ymin, ymax=ymax, umin=umin, umax=umax, Q=np.diag([1000.0, 10.0]), R=1.0, rho=1000.0, Nc=Nc)
+
+
+def state_disc_model(seed=0, nl_scale=0.05):
+    """A full-state model of the unbalanced disc for the state-feedback controllers (the reference's
+    trained state model, systems/UnbalancedDisk_dt01_e100_SNR_100, is not part of its repository):
+    linear skip = the plant's discrete linearisation at rest in normalised coordinates, nonlinear
+    branch = small random weights.  Returns (oracle Model, y0[2], ystd[2])."""
+    import numpy as np
+    from oracle.model import Model, ResNet
+    from oracle.plant import disc_step
+    y0 = np.zeros(2); ystd = np.array([5.0, 0.6]); u0, ustd = 0.0, 1.5
+    eps = 1e-6; dt = 0.1
+    f = lambda z: (disc_step(z[:2] * ystd + y0, z[2] * ustd + u0, dt) - y0) / ystd
+    J = np.stack([(f(np.eye(3)[i] * eps) - f(-np.eye(3)[i] * eps)) / (2 * eps) for i in range(3)], axis=1)
+    rng = np.random.default_rng(seed)
+    g = lambda r, c: (rng.standard_normal((r, c)) / np.sqrt(c)).astype(np.float32)
+    b = lambda r: (0.1 * rng.standard_normal(r)).astype(np.float32)
+    fn = ResNet(J.astype(np.float32), np.zeros(2, np.float32), g(64, 3), b(64), g(64, 64), b(64), nl_scale * g(2, 64), b(2))
+    hn = ResNet(np.array([[0.0, 1.0]], np.float32), np.zeros(1, np.float32), g(64, 2), b(64), g(64, 64), b(64),
+                0.0 * g(1, 64), np.zeros(1, np.float32))
+    return Model(fn, hn, None, u0=u0, ustd=ustd, y0=0.0, ystd=1.0), y0, ystd

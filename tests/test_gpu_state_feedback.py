@@ -1,0 +1,96 @@
+"""GPU parity tests of the state-feedback controllers (par_NMPC_linear, NMPC_linear: NMPC.py:374-650)
+and the state-constrained target selector (getXsUs, mpcUtil.py:167-239) through the C ABI against the
+fp64 oracle.  The reference's trained full-state model is not part of its repository, so the model is
+the synthetic disc model of conftest.state_disc_model; bars as for the output-feedback loop:
+targets 1e-5, closed-loop trajectories 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lpv as olpv
+from oracle.nmpc import state_nmpc_linear, target_selector_state
+from oracle.plant import random_level_reference
+from conftest import state_disc_model
+
+pytestmark = pytest.mark.gpu
+XMIN, XMAX, UMIN, UMAX = [-8.0, -2.0], [8.0, 2.0], -6.0, 6.0
+
+
+@pytest.fixture(scope="module")
+def smodel():
+    import nmpc_amd
+    om, y0, ystd = state_disc_model()
+    params = {k: [np.asarray(a, np.float32) for a in n.params()] for k, n in (("fn", om.fn), ("hn", om.hn))}
+    enc = nmpc_amd.Encoder(params, nmpc_amd.Norm(om.u0, om.ustd, y0, ystd), device="cuda:0")
+    return om, enc, y0, ystd
+
+
+def test_getXsUs_vs_oracle(smodel):
+    import nmpc_amd
+    om, enc, y0, ystd = smodel
+    B, Ns = 3, 45
+    refs = np.stack([random_level_reference(Ns, [10, 15], [-1, 1], np.random.default_rng(40 + b)) for b in range(B)])
+    refs[1] *= 2.5                                           # beyond the state box: the slack takes over
+    yrn = (refs - y0[1]) / ystd[1]
+    xmin = (np.array(XMIN) - y0) / ystd; xmax = (np.array(XMAX) - y0) / ystd
+    umin, umax = (UMIN - om.u0) / om.ustd, (UMAX - om.u0) / om.ustd
+    lam, w = nmpc_amd.quad_nodes("simpson", 20, 0.05)
+    Xs, Us, Es, it = nmpc_amd.getXsUs(yrn, 2, 1, 1, Ns, umin, umax, xmin, xmax, nmpc_amd.GetABC(enc, lam, w), None,
+                                      np.array([[0.0, 1.0]]), None, np.zeros(1), return_iters=True)
+    nodes, weights = olpv.merge_nodes(*olpv.quad_nodes("simpson", 20, 0.05))
+    for b in range(B):
+        xo, uo, eo, ito = target_selector_state(om, yrn[b], Ns, umin, umax, xmin, xmax, np.array([[0.0, 1.0]]), nodes, weights)
+        assert np.abs(Xs[b].cpu().numpy() - xo).max() < 1e-5 and np.abs(Us[b].cpu().numpy() - uo).max() < 1e-5
+        assert np.abs(Es[b].cpu().numpy() - eo).max() < 1e-5
+        assert (it[b].cpu().numpy() == ito).mean() > 0.9
+    assert Es[1].max() > 1e-3 and float(Es[0].abs().max()) < 1e-9
+
+
+def test_par_NMPC_linear_vs_oracle(smodel):
+    """Tracking with soft state constraints, measurement noise on both states, up to 5 passes."""
+    import nmpc_amd
+    om, enc, y0, ystd = smodel
+    B, Nsim, Nc = 3, 40, 10
+    Q = np.diag([1.0, 1000.0])
+    refs = np.stack([np.vstack([np.zeros(Nsim + Nc), random_level_reference(Nsim + Nc, [10, 15], [-1, 1], np.random.default_rng(60 + b))])
+                     for b in range(B)])
+    refs[:, 1] *= 0.6                                        # the synthetic model is the disc's linearisation at rest
+    refs[2, 1] *= 1.3                                        # asks for angles outside the box below
+    xmin, xmax = [-8.0, -0.5], [8.0, 0.5]
+    noise = np.random.default_rng(5).standard_normal((Nsim, B, 2)) * np.array([0.05, 0.005])
+    plant = nmpc_amd.NoisyUnbalancedDisc(dt=0.1, sigma_n=[0.05, 0.005])
+    out = nmpc_amd.par_NMPC_linear(plant, enc, xmin, xmax, UMIN, UMAX, [0.0, 0.0], 0, Q, 1.0, 0.1, 0.05, 20, refs, Nc=Nc,
+                                   Nsim=Nsim, max_iterations=5, noise=noise)
+    x_log, u_log, e_log, comp_t, t, runtime, lpvc, refn, ct = out
+    assert x_log.shape == (B, (Nsim + 1) * 2) and u_log.shape == (B, Nsim) and ct.shape == (4, Nsim * 5)
+    for b in range(B):
+        o = state_nmpc_linear(om, xmin, xmax, UMIN, UMAX, [0.0, 0.0], Q, 1.0, 0.1, 0.05, 20, refs[b], Nc=Nc, Nsim=Nsim,
+                              max_iterations=5, noise=noise[:, b], y0=y0, ystd=ystd)
+        assert np.abs(x_log[b].cpu().numpy().reshape(Nsim + 1, 2) - o["x_log"]).max() < 1e-4
+        assert np.abs(u_log[b].cpu().numpy() - o["u_log"]).max() < 1e-4
+        assert np.abs(e_log[b, 0].cpu().numpy() - o["e_log"]).max() < 1e-4
+        assert (lpvc[b].cpu().numpy() == o["lpv_counter"]).mean() > 0.9
+    assert float(e_log[2].abs().max()) > 1e-3               # the slack was needed for controller 2
+    # un-batched call, as the reference makes it
+    o1 = nmpc_amd.par_NMPC_linear(plant, enc, xmin, xmax, UMIN, UMAX, [0.0, 0.0], 0, Q, 1.0, 0.1, 0.05, 20, refs[0], Nc=Nc,
+                                  Nsim=Nsim, max_iterations=5, noise=noise[:, :1])
+    assert o1[0].shape == ((Nsim + 1) * 2,) and torch.equal(o1[1], u_log[0])
+
+
+def test_NMPC_linear_vs_oracle(smodel):
+    """Regulation to the origin with hard constraints (no slack variable): the input bound is active
+    during the first steps."""
+    import nmpc_amd
+    om, enc, y0, ystd = smodel
+    Nsim, Nc = 25, 10
+    Q = np.diag([100.0, 100.0])
+    x0 = [3.0, 1.2]
+    plant = nmpc_amd.NoisyUnbalancedDisc(dt=0.1, sigma_n=[0.0, 0.0])
+    out = nmpc_amd.NMPC_linear(plant, enc, XMIN, XMAX, -2.0, 2.0, x0, 0, Q, 1.0, 0.1, 0.05, 20, None, Nc=Nc, Nsim=Nsim,
+                               max_iterations=5)
+    o = state_nmpc_linear(om, XMIN, XMAX, -2.0, 2.0, x0, Q, 1.0, 0.1, 0.05, 20, None, Nc=Nc, Nsim=Nsim, max_iterations=5,
+                          tol=1e-7, rho=None, y0=y0, ystd=ystd)
+    assert np.abs(out[0].cpu().numpy().reshape(Nsim + 1, 2) - o["x_log"]).max() < 1e-4
+    assert np.abs(out[1].cpu().numpy() - o["u_log"]).max() < 1e-4
+    assert np.abs(out[1].cpu().numpy()).max() > 2.0 - 1e-6 and np.abs(out[1].cpu().numpy()).max() < 2.0 + 1e-9
+    assert out[8].shape == (4,) and np.abs(o["x_log"][-1]).max() < 1e-3

@@ -196,3 +196,18 @@ def test_mpc_qp_matches_generic_form(omodel):
     assert np.allclose(pc["h"], c[:, 0] - D @ [ym] - M @ Z @ (Phi @ x0 + F0) - M @ H0)
     assert np.allclose(xp, Phi @ x0 + Gam @ u + F0)
     assert np.all(pc["Le"] @ np.append(u, eps) <= pc["h"] + 1e-9)
+
+
+def test_state_feedback_oracle_tracks():
+    """State-feedback restatements (NMPC.py:374-650): tracking with soft constraints follows the
+    reference levels, regulation with hard constraints returns to the origin with |u| <= bound."""
+    from conftest import state_disc_model
+    from oracle.nmpc import state_nmpc_linear
+    om, y0, ystd = state_disc_model()
+    ref = np.vstack([np.zeros(60), 0.6 * random_level_reference(60, [10, 15], [-1, 1], np.random.default_rng(3))])
+    o = state_nmpc_linear(om, [-8, -2], [8, 2], -6, 6, [0.0, 0.0], np.diag([1.0, 1000.0]), 1.0, 0.1, 0.05, 20, ref, Nc=10,
+                          Nsim=40, max_iterations=5, y0=y0, ystd=ystd)
+    assert np.median(np.abs(o["x_log"][10:41:5, 1] - ref[1, 9:40:5])) < 0.1
+    r = state_nmpc_linear(om, [-8, -2], [8, 2], -2, 2, [3.0, 1.2], np.diag([100.0, 100.0]), 1.0, 0.1, 0.05, 20, None, Nc=10,
+                          Nsim=25, max_iterations=5, tol=1e-7, rho=None, y0=y0, ystd=ystd)
+    assert np.abs(r["x_log"][-1]).max() < 1e-3 and np.abs(r["u_log"]).max() <= 2 + 1e-9 and np.abs(r["u_log"]).max() > 2 - 1e-6
