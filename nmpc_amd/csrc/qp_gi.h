@@ -263,10 +263,10 @@ __device__ __forceinline__ int gi_solve(int n, int mt, int meq, QPWork& w, doubl
     }
     g_sync();
     if (stamp && gl == 0) stamp[1] = __builtin_amdgcn_s_memtime();
-    // FAST: one problem per wave and n <= NMAX.  Loops over the n variables run in unrolled chunks with
+    // FAST: one problem per wave (n <= 64).  Loops over the n variables run in unrolled chunks with
     // clamped addresses (a chunk's loads are in flight together), group broadcasts are v_readlane, and the
     // primal step keeps its direction in registers instead of LDS.
-    constexpr bool FAST = GS == 64 && NMAX > 0;
+    constexpr bool FAST = GS == 64;
     constexpr int UNR = 4;   // loads in flight per chunk of the n-loops
     double s[MPL], sgn[MPL], iscale[MPL];
     unsigned amask = 0;

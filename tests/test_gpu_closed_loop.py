@@ -203,3 +203,19 @@ def test_closed_loop_long_horizon(enc, omodel):
     assert np.abs(out[8].cpu().numpy() - st("y_log")).max() < 1e-4
     assert np.abs(out[1].cpu().numpy() - st("u_log")).max() < 1e-4
     assert (out[6].cpu().numpy() == st("lpv_counter")).mean() > 0.9
+
+
+def test_recorded_closed_loop_of_the_reference(enc):
+    """The reference's recorded run (Experiments/log_q.npy, log_w.npy on randomLevelTime25_30Range-1_1Nsim500):
+    loose pin, see the oracle's test of the same name; here the device loop against the record."""
+    import nmpc_amd
+    from test_oracle import recorded_run_windows
+    q = np.load(os.path.join(GOLDEN, "ref_log_q.npy"))[0]; w = np.load(os.path.join(GOLDEN, "ref_log_w.npy"))[0]
+    r = np.load(os.path.join(GOLDEN, "ref_randomLevelTime25_30Range-1_1Nsim500.npy"))
+    plant = nmpc_amd.OutputUnbalancedDisc(dt=0.1, sigma_n=[0.0])
+    out = nmpc_amd.output_NMPC_linear(plant, enc, -4, 4, [-1.2], [1.2], np.zeros(2), Q, 1.0, 0.1, 0.05, 20,
+                                      np.clip(r[1], -1.2, 1.2), Nc=10, Nsim=450, max_iterations=4)
+    y = out[8].cpu().numpy()[1:]; u = out[1].cpu().numpy()
+    idx = recorded_run_windows(r[1], 450)
+    assert np.abs(y[idx] - q[idx]).max() < 5e-3 and np.abs(u[idx] - w[idx]).max() < 2e-2
+    assert np.median(np.abs(y - q)) < 6e-3
