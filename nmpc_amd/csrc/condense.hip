@@ -132,10 +132,10 @@ using namespace nmpc;
 extern "C" int nmpc_condense(int nb, int Nc, int nx, int nu, const double* list_A, const double* list_B,
                              const double* f0, double* Phi, double* Gamma, double* F0, void* stream) {
     NMPC_REQUIRE(nb >= 0 && Nc >= 1 && nu >= 1, "nmpc_condense: bad sizes");
+    if (nb == 0) return 0;                       // an empty batch may come with null pointers
     NMPC_REQUIRE(list_A, "nmpc_condense: list_A is null");
     NMPC_REQUIRE(!Gamma || list_B, "nmpc_condense: Gamma needs list_B");
     NMPC_REQUIRE(!F0 || f0, "nmpc_condense: F0 needs f0");
-    if (nb == 0) return 0;
     const int threads = 128, grid = (nb * Nc + threads - 1) / threads;
 #define CALL(NX_) hipLaunchKernelGGL((condense_kernel<NX_>), dim3(grid), dim3(threads), 0, (hipStream_t)stream, nb, Nc, nu, list_A, list_B, f0, Phi, Gamma, F0);
     NMPC_NX_SWITCH(nx, CALL)
@@ -147,8 +147,8 @@ extern "C" int nmpc_condense(int nb, int Nc, int nx, int nu, const double* list_
 extern "C" int nmpc_lpv_rk4(int n, int nx, int nu, const double* x, const double* u, const double* A,
                             const double* B, double dt, const double* c, double* xnext, void* stream) {
     NMPC_REQUIRE(n >= 0 && nu >= 1, "nmpc_lpv_rk4: bad sizes");
-    NMPC_REQUIRE(x && u && A && B && c && xnext, "nmpc_lpv_rk4: null argument");
     if (n == 0) return 0;
+    NMPC_REQUIRE(x && u && A && B && c && xnext, "nmpc_lpv_rk4: null argument");
     const int threads = 128, grid = (n + threads - 1) / threads;
 #define CALL(NX_) hipLaunchKernelGGL((lpv_rk4_kernel<NX_>), dim3(grid), dim3(threads), 0, (hipStream_t)stream, n, nu, x, u, A, B, dt, c, xnext);
     NMPC_NX_SWITCH(nx, CALL)

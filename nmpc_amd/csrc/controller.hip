@@ -717,8 +717,8 @@ extern "C" int nmpc_mpc_qp(int nb, int Nc, int nx, const double* list_A, const d
                            double u_max, double y_min, double y_max, double* Ge, double* Fe, double* Le, double* hv,
                            double* u, double* eps, double* xpred, int* status, void* stream) {
     NMPC_REQUIRE(nb >= 0, "nmpc_mpc_qp: negative batch");
-    NMPC_REQUIRE(list_A && list_B && list_C && x0 && y_meas && Xs && Us && f0 && Q, "nmpc_mpc_qp: null input");
     if (nb == 0) return 0;
+    NMPC_REQUIRE(list_A && list_B && list_C && x0 && y_meas && Xs && Us && f0 && Q, "nmpc_mpc_qp: null input");
     MpcGeom g;
     if (mpc_geom(Nc, nx, 0, 1, g)) return 1;
     MpcQpArgs a{};

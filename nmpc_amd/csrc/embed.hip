@@ -491,6 +491,8 @@ extern "C" int nmpc_lpv_embed(const nmpc_model* m, int npts, const float* x, con
     NMPC_REQUIRE(m && lam && w, "nmpc_lpv_embed: null argument");
     NMPC_REQUIRE(n_nodes >= 1 && n_nodes <= NMPC_MAX_NODES, "nmpc_lpv_embed: n_nodes=%d out of [1,%d]", n_nodes,
                  NMPC_MAX_NODES);
+    NMPC_REQUIRE(npts >= 0, "nmpc_lpv_embed: negative point count");
+    if (npts == 0) return 0;                     // an empty batch may come with null pointers
     NodeTable nt;
     nt.n = n_nodes;
     for (int i = 0; i < NMPC_MAX_NODES; ++i) { nt.lam[i] = i < n_nodes ? lam[i] : 0.f; nt.w[i] = i < n_nodes ? w[i] : 0.f; }

@@ -101,11 +101,11 @@ extern "C" int nmpc_qp_solve(int nb, int n, int m, int meq, const double* P, con
                              const double* h, const double* Aeq, const double* beq, double* z, double* lambda,
                              int* status, int* iters, void* stream) {
     NMPC_REQUIRE(nb >= 0 && n >= 1 && m >= 0 && meq >= 0, "nmpc_qp_solve: bad sizes");
+    if (nb == 0) return 0;                       // an empty batch may come with null pointers
     NMPC_REQUIRE(P && q && z && status, "nmpc_qp_solve: null argument");
     NMPC_REQUIRE(m == 0 || (G && h), "nmpc_qp_solve: G/h missing");
     NMPC_REQUIRE(meq == 0 || (Aeq && beq), "nmpc_qp_solve: Aeq/beq missing");
     NMPC_REQUIRE(meq <= n, "nmpc_qp_solve: more equalities than variables");
-    if (nb == 0) return 0;
     QPArgs a{nb, n, m, meq, P, q, G, h, Aeq, beq, z, lambda, status, iters};
     return qp_launch(a, (hipStream_t)stream);
 }

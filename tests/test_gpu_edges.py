@@ -1,0 +1,40 @@
+"""Degenerate sizes through the C ABI: empty batches, one controller, horizon 1, zero steps."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.nmpc import output_nmpc_linear
+from oracle.plant import random_level_reference
+
+pytestmark = pytest.mark.gpu
+Q = np.diag([1000.0, 10.0])
+
+
+def test_empty_batches(enc):
+    import nmpc_amd
+    lam, w = nmpc_amd.quad_nodes("simpson", 20)
+    A, B, C = nmpc_amd.embed(enc, torch.zeros(0, 2), torch.zeros(0, 1), torch.zeros(0, 2), lam, w)
+    assert A.shape == (0, 2, 2) and B.shape == (0, 2, 1) and C.shape == (0, 1, 2)
+    assert nmpc_amd.getPhi(np.zeros((0, 20, 2)), 10, 2, 1).shape == (0, 20, 2)
+    assert nmpc_amd.getGamma(np.zeros((0, 20, 2)), np.zeros((0, 20, 1)), 10, 2, 1).shape == (0, 20, 10)
+    z = nmpc_amd.solve_qp(np.zeros((0, 3, 3)), np.zeros((0, 3)))
+    assert z.shape == (0, 3)
+
+
+@pytest.mark.parametrize("Nc", [1, 2])
+def test_short_horizons_single_controller(enc, omodel, Nc):
+    """B = 1, Nc = 1 and 2 (2- and 3-variable QPs, 6 and 10 rows) against the oracle."""
+    import nmpc_amd
+    Nsim = 12
+    ref = random_level_reference(Nsim + Nc, [10, 15], [-1, 1], np.random.default_rng(8))
+    o = output_nmpc_linear(omodel, -4, 4, [-1.2], [1.2], np.zeros(2), Q, 1.0, 0.1, 20, ref, Nc=Nc, Nsim=Nsim, max_iterations=4)
+    plant = nmpc_amd.OutputUnbalancedDisc(dt=0.1, sigma_n=[0.0])
+    out, ctrl = nmpc_amd.output_NMPC_linear(plant, enc, -4, 4, [-1.2], [1.2], np.zeros(2), Q, 1.0, 0.1, 0.05, 20, ref, Nc=Nc,
+                                            Nsim=Nsim, max_iterations=4, return_controller=True)
+    assert np.abs(out[8].cpu().numpy() - o["y_log"]).max() < 1e-4 and np.abs(out[1].cpu().numpy() - o["u_log"]).max() < 1e-4
+    before = {k: v.clone() for k, v in ctrl.logs.items()}
+    ctrl.run(Nsim, 0)                                    # zero steps: nothing launched, nothing written
+    torch.cuda.synchronize()
+    assert all(torch.equal(before[k], ctrl.logs[k]) for k in before)
+    with pytest.raises(nmpc_amd.NmpcError):
+        ctrl.run(Nsim, 1)                                # beyond n_sim
