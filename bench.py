@@ -123,6 +123,8 @@ def main():
                     help="bracket the kernel launches of every n-th step with HIP event pairs")
     ap.add_argument("--cpu-controllers", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=120)
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="diagnostic: run the N-rank path with every rank on cuda:0 and the gloo backend")
     args = ap.parse_args()
 
     import torch
@@ -134,10 +136,15 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
                          % (args.gpus, args.gpus))
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     B, K, W = args.batch, args.steps, args.warmup
     nsim = K + W

@@ -28,6 +28,9 @@ def gather_logs(local, total=None, group=None):
         return dict(local)
     world = dist.get_world_size(group)
     any_t = next(iter(local.values()))
+    if dist.get_backend(group) != "nccl" and any_t.is_cuda:      # gloo: stage through host memory
+        host = gather_logs({k: v.cpu() for k, v in local.items()}, total, group)
+        return {k: v.to(any_t.device) for k, v in host.items()}
     n_local = torch.tensor([any_t.shape[0]], device=any_t.device, dtype=torch.int64)
     sizes = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(sizes, n_local, group=group)
