@@ -39,6 +39,21 @@ constexpr int PK_J0 = 21008;      // [4][4]  Jacobian of the nonlinear branch at
 constexpr int PACK_FLOATS = 21024;
 constexpr int PK_TAIL = PACK_FLOATS - PK_REC1;   // REC1 + REC2 + LIN + J0, contiguous
 
+// One net in the layout of the general-width embedding kernel (embed_wide.hip); hidden width padded
+// to 16*ht (ht = 4, 8, 16), outputs padded to nout_pad (1, 4, 8), inputs to 16; all fp32, device.
+struct WideNet {
+    const float* fwd;   // [ht][ht][64][4]  A-fragments of c2*W2:  W[16T + (l&15)][16S + 4(l>>4) + j]
+    const float* rev;   // [ht][ht][64][4]  A-fragments of W2^T
+    const float* w0t;   // [ht][64][4]      A-fragments of W0^T:   W0[16T + 4(l>>4) + j][l&15]
+    const float* w0;    // [H][16]          W0 rows
+    const float* cb0;   // [H]  c2*b0
+    const float* cb2;   // [H]  c2*b2
+    const float* w4s;   // [nout_pad][H]    4*W4
+    const float* lin;   // [nout_pad][16]   W_lin
+    const float* j0;    // [nout_pad][16]   nonlinear-branch Jacobian at the origin (fp64-evaluated)
+    int ht, nout_pad;
+};
+
 // Device-resident packed networks.
 struct ModelDev {
     int nx, nu, ny, hidden, n_enc_in;
@@ -46,6 +61,9 @@ struct ModelDev {
     float* hpack;   // h-net, fp32 MFMA layout
     float* fpack_h2;   // f-net, split-fp16 MFMA layout (same offsets, fragment regions hold halves)
     float* hpack_h2;   // h-net, split-fp16 MFMA layout
+    WideNet wide_f, wide_h;   // both nets for the general-width kernel
+    float* wide_slab;         // their storage
+    int narrow_ok;            // the 64-wide kernels cover this model's sizes
     float* enc;     // observer net, plain row-major params concatenated (may be null):
                     // lin_w[out,in] lin_b w0[H,in] b0 w2[H,H] b2 w4[out,H] b4 w2^T[H,H]
     float* hplain;  // h-net in the same plain layout (for the output estimate)

@@ -35,5 +35,7 @@ struct EmbedArgs {
 };
 
 int embed_launch(const ModelDev& m, EmbedArgs a, const NodeTable& nt, hipStream_t stream, bool loop = false);
+// general-width kernel (embed_wide.hip); nt must already have its lambda = 0 nodes folded into w_zero
+int embed_wide_launch(const ModelDev& m, const EmbedArgs& a, const NodeTable& nt, hipStream_t stream, bool loop);
 
 }  // namespace nmpc

@@ -436,16 +436,17 @@ static int embed_launch_t(const EmbedArgs& a, const NodeTable& nt, int grid, siz
     return 0;
 }
 
-// NMPC_EMBED=f32 selects the fp32-MFMA kernel, anything else the split-fp16 kernel (when the model's
-// weights suit it: see pack_net_h2)
-static bool embed_use_h2() {
+// NMPC_EMBED=f32 selects the fp32-MFMA kernel, NMPC_EMBED=wide the general-width kernel, anything else
+// the split-fp16 kernel (when the model's weights suit it: see pack_net_h2)
+static int embed_mode() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("NMPC_EMBED");
-        v = (e && std::string(e) == "f32") ? 0 : 1;
+        v = (e && std::string(e) == "f32") ? 0 : ((e && std::string(e) == "wide") ? 2 : 1);
     }
-    return v == 1;
+    return v;
 }
+static bool embed_use_h2() { return embed_mode() == 1; }
 
 int embed_launch(const ModelDev& m, EmbedArgs a, const NodeTable& nodes, hipStream_t stream, bool loop) {
     NMPC_REQUIRE(nodes.n >= 1 && nodes.n <= NMPC_MAX_NODES, "embed: node count %d out of range", nodes.n);
@@ -459,6 +460,8 @@ int embed_launch(const ModelDev& m, EmbedArgs a, const NodeTable& nodes, hipStre
     if (a.npts == 0) return 0;
     const bool do_f = a.x && a.u && a.A && a.B, do_h = a.xc && a.C;
     NMPC_REQUIRE(do_f || do_h, "embed: nothing to compute (need x,u,A,B and/or xc,C)");
+    if (a.group < 1) a.group = 1;
+    if (!m.narrow_ok || embed_mode() == 2) return embed_wide_launch(m, a, nt, stream, loop);
     const int tiles = (a.npts + EMBED_TILE - 1) / EMBED_TILE;
     const bool h2 = embed_use_h2() && m.fpack_h2 && m.hpack_h2;
     a.fpack = h2 ? m.fpack_h2 : m.fpack; a.hpack = h2 ? m.hpack_h2 : m.hpack;

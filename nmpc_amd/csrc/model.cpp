@@ -109,6 +109,65 @@ static bool pack_net_h2(const float* const* p, int n_in, int n_out, std::vector<
     return ok;
 }
 
+// Layout of the general-width kernel (embed_wide.hip): see WideNet in common.h.  Appends the
+// net's arrays to `slab` (floats) and records the offsets in `off` (fwd, rev, w0t, w0, cb0, cb2, w4s,
+// lin, j0).  hidden is padded with zero units to 16*ht, outputs with zero rows to nout_pad.
+static void pack_wide(const float* const* p, int n_in, int n_out, int hidden, int ht, int nout_pad,
+                      std::vector<float>& slab, size_t off[9]) {
+    const float *lin_w = p[0], *w0 = p[2], *b0 = p[3], *w2 = p[4], *b2 = p[5], *w4 = p[6];
+    const double c2 = 2.0 * 1.4426950408889634074;
+    const int H = 16 * ht;
+    auto W2 = [&](int i, int k) { return (i < hidden && k < hidden) ? (double)w2[(size_t)i * hidden + k] : 0.0; };
+    auto grab = [&](size_t nfl) { const size_t o = slab.size(); slab.resize(o + ((nfl + 3) & ~(size_t)3), 0.0f); return o; };
+    off[0] = grab((size_t)ht * ht * 256); off[1] = grab((size_t)ht * ht * 256); off[2] = grab((size_t)ht * 256);
+    off[3] = grab((size_t)H * 16); off[4] = grab(H); off[5] = grab(H); off[6] = grab((size_t)nout_pad * H);
+    off[7] = grab((size_t)nout_pad * 16); off[8] = grab((size_t)nout_pad * 16);
+    for (int T = 0; T < ht; ++T)
+        for (int S = 0; S < ht; ++S)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 4; ++j) {
+                    const size_t o = (((size_t)T * ht + S) * 64 + l) * 4 + j;
+                    const int r = 16 * T + (l & 15), c = 16 * S + 4 * (l >> 4) + j;
+                    slab[off[0] + o] = (float)(c2 * W2(r, c));
+                    slab[off[1] + o] = (float)W2(c, r);                 // W2^T[r][c]
+                }
+    for (int T = 0; T < ht; ++T)
+        for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 4; ++j) {
+                const int k = 16 * T + 4 * (l >> 4) + j, jn = l & 15;
+                slab[off[2] + ((size_t)T * 64 + l) * 4 + j] = (k < hidden && jn < n_in) ? w0[(size_t)k * n_in + jn] : 0.0f;
+            }
+    for (int k = 0; k < hidden; ++k) {
+        for (int j = 0; j < n_in; ++j) slab[off[3] + (size_t)k * 16 + j] = w0[(size_t)k * n_in + j];
+        slab[off[4] + k] = (float)(c2 * (double)b0[k]);
+        slab[off[5] + k] = (float)(c2 * (double)b2[k]);
+        for (int c = 0; c < n_out; ++c) slab[off[6] + (size_t)c * H + k] = 4.0f * w4[(size_t)c * hidden + k];
+    }
+    for (int c = 0; c < n_out; ++c)
+        for (int j = 0; j < n_in; ++j) slab[off[7] + (size_t)c * 16 + j] = lin_w[(size_t)c * n_in + j];
+    // nonlinear-branch Jacobian at the origin (fp64)
+    std::vector<double> t1(hidden), d2(hidden), v(hidden);
+    for (int k = 0; k < hidden; ++k) t1[k] = std::tanh((double)b0[k]);
+    for (int i = 0; i < hidden; ++i) {
+        double a = b2[i];
+        for (int k = 0; k < hidden; ++k) a += (double)w2[(size_t)i * hidden + k] * t1[k];
+        const double t = std::tanh(a);
+        d2[i] = 1.0 - t * t;
+    }
+    for (int c = 0; c < n_out; ++c) {
+        for (int k = 0; k < hidden; ++k) {
+            double a = 0.0;
+            for (int i = 0; i < hidden; ++i) a += (double)w4[(size_t)c * hidden + i] * d2[i] * (double)w2[(size_t)i * hidden + k];
+            v[k] = a * (1.0 - t1[k] * t1[k]);
+        }
+        for (int j = 0; j < n_in; ++j) {
+            double a = 0.0;
+            for (int k = 0; k < hidden; ++k) a += v[k] * (double)w0[(size_t)k * n_in + j];
+            slab[off[8] + (size_t)c * 16 + j] = (float)a;
+        }
+    }
+}
+
 static void eval_net_at_zero(const float* const* p, int n_in, int n_out, int hidden, double* y) {
     std::vector<double> t1(hidden), t2(hidden);
     for (int k = 0; k < hidden; ++k) t1[k] = std::tanh((double)p[3][k]);
@@ -136,16 +195,42 @@ extern "C" int nmpc_model_create(nmpc_model** out, int nx, int nu, int ny, int h
                                  const float* const* fn, const float* const* hn,
                                  const float* const* enc) {
     NMPC_REQUIRE(out && fn && hn, "nmpc_model_create: null argument");
-    NMPC_REQUIRE(hidden == HID, "nmpc_model_create: hidden width %d unsupported (kernel is built for %d)",
-                 hidden, HID);
-    NMPC_REQUIRE(nx >= 1 && nu >= 1 && ny >= 1 && nx + nu <= 4 && nx <= 4 && ny <= 4,
-                 "nmpc_model_create: dims nx=%d nu=%d ny=%d unsupported (need nx+nu<=4, ny<=4)", nx, nu, ny);
+    NMPC_REQUIRE(hidden >= 1 && hidden <= 256, "nmpc_model_create: hidden width %d unsupported (1..256)", hidden);
+    NMPC_REQUIRE(nx >= 1 && nu >= 1 && ny >= 1 && nx <= 8 && nx + nu <= 16 && ny <= 8,
+                 "nmpc_model_create: dims nx=%d nu=%d ny=%d unsupported (need nx<=8, nx+nu<=16, ny<=8)", nx, nu, ny);
+    // the 64-wide kernels (embed.hip) are instantiated for these sizes; everything else runs on the
+    // general-width kernel (embed_wide.hip)
+    const bool narrow = hidden == HID && nu == 1 && ny == 1 && (nx == 2 || nx == 3);
     NMPC_REQUIRE(!enc || (n_enc_in >= 1 && n_enc_in <= 32), "nmpc_model_create: bad encoder input size %d",
                  n_enc_in);
     nmpc_model* m = new nmpc_model();
     std::memset(m, 0, sizeof(*m));
     m->d.nx = nx; m->d.nu = nu; m->d.ny = ny; m->d.hidden = hidden; m->d.n_enc_in = enc ? n_enc_in : 0;
     NMPC_HIP_CHECK(hipGetDevice(&m->device));
+    m->d.narrow_ok = narrow ? 1 : 0;
+    {
+        const int ht = hidden <= 64 ? 4 : (hidden <= 128 ? 8 : 16);
+        auto padout = [](int n) { return n <= 1 ? 1 : (n <= 4 ? 4 : 8); };
+        std::vector<float> slab;
+        size_t of[9], oh[9];
+        pack_wide(fn, nx + nu, nx, hidden, ht, padout(nx), slab, of);
+        pack_wide(hn, nx, ny, hidden, ht, padout(ny), slab, oh);
+        NMPC_HIP_CHECK(hipMalloc(&m->d.wide_slab, slab.size() * sizeof(float)));
+        NMPC_HIP_CHECK(hipMemcpy(m->d.wide_slab, slab.data(), slab.size() * sizeof(float), hipMemcpyHostToDevice));
+        auto bind = [&](WideNet& w, const size_t* o, int nout_pad) {
+            const float* b = m->d.wide_slab;
+            w.fwd = b + o[0]; w.rev = b + o[1]; w.w0t = b + o[2]; w.w0 = b + o[3]; w.cb0 = b + o[4]; w.cb2 = b + o[5];
+            w.w4s = b + o[6]; w.lin = b + o[7]; w.j0 = b + o[8]; w.ht = ht; w.nout_pad = nout_pad;
+        };
+        bind(m->d.wide_f, of, padout(nx)); bind(m->d.wide_h, oh, padout(ny));
+    }
+    eval_net_at_zero(fn, nx + nu, nx, hidden, m->d.f0);
+    eval_net_at_zero(hn, nx, ny, hidden, m->d.h0);
+    if (!narrow) {           // no 64-wide packs, no plain nets for the closed-loop observer
+        NMPC_REQUIRE(!enc, "nmpc_model_create: an observer net needs hidden = 64, nu = ny = 1, nx = 2 or 3");
+        *out = m;
+        return 0;
+    }
     std::vector<float> buf;
     pack_net(fn, nx + nu, nx, buf);
     NMPC_HIP_CHECK(hipMalloc(&m->d.fpack, PACK_FLOATS * sizeof(float)));
@@ -161,8 +246,6 @@ extern "C" int nmpc_model_create(nmpc_model** out, int nx, int nu, int ny, int h
         NMPC_HIP_CHECK(hipMalloc(&m->d.hpack_h2, PACK_FLOATS * sizeof(float)));
         NMPC_HIP_CHECK(hipMemcpy(m->d.hpack_h2, buf2.data(), PACK_FLOATS * sizeof(float), hipMemcpyHostToDevice));
     }
-    eval_net_at_zero(fn, nx + nu, nx, hidden, m->d.f0);
-    eval_net_at_zero(hn, nx, ny, hidden, m->d.h0);
     auto upload_plain = [&](const float* const* p, int n_in, int n_out, float** dst) -> int {
         const int sz[8] = {n_out * n_in, n_out, hidden * n_in, hidden, hidden * hidden, hidden, n_out * hidden, n_out};
         std::vector<float> e;
@@ -187,6 +270,7 @@ extern "C" void nmpc_model_destroy(nmpc_model* m) {
     if (m->d.hpack_h2) (void)hipFree(m->d.hpack_h2);
     if (m->d.enc) (void)hipFree(m->d.enc);
     if (m->d.hplain) (void)hipFree(m->d.hplain);
+    if (m->d.wide_slab) (void)hipFree(m->d.wide_slab);
     delete m;
 }
 

@@ -81,6 +81,8 @@ class Controller:
                  nodes, weights, tol=1e-1, rho=1000.0, state_feedback=None):
         """state_feedback: None for the output-feedback controller, or a dict(x_min, x_max [nx] normalised
         state bounds, y0, ystd [nx] state normalisation, hard=bool) for the state-feedback controllers."""
+        if encoder.nx > 4:
+            raise _lib.NmpcError("closed-loop controllers support nx <= 4 (model has nx = %d)" % encoder.nx)
         cfg = _lib.CtrlConfig()
         cfg.batch, cfg.Nc, cfg.max_iterations, cfg.n_sim = int(batch), int(Nc), int(max_iterations), int(Nsim)
         cfg.tol, cfg.rho = float(tol), float(rho)

@@ -152,3 +152,50 @@ def test_ablist_family_on_golden(enc, golden):
     assert np.abs(a1.cpu().numpy() - g["list_A"][1]).max() < 1e-5
     pA = Get_A(x[1].reshape(Nc, nx).T, u[1])
     assert pA.shape == (nx, Nc * nx) and np.abs(pA[:, 2:4].cpu().numpy() - g["list_A"][1][2:4]).max() < 1e-5
+
+
+@pytest.mark.parametrize("nx,nu,ny,H", [(4, 1, 1, 64), (8, 1, 3, 64), (3, 2, 2, 128), (8, 1, 1, 256), (5, 1, 2, 100)])
+def test_wide_nets(nx, nu, ny, H):
+    """Nets beyond the 64-wide kernels (deepSI encoders with nx = 4 and 8: LTI.ipynb cell 5, sinCos.ipynb
+    cell 6; the synthetic nx = 8 / H = 256 configuration) run on the general-width kernel: exact-fp32
+    MFMA with weight fragments streamed from L2.  H = 100 exercises the zero padding of hidden units."""
+    import nmpc_amd
+    from oracle.model import Model
+    om = Model.synthetic(nx, nu, ny, H, seed=3)
+    params = {k: [np.asarray(a, np.float32) for a in n.params()] for k, n in (("fn", om.fn), ("hn", om.hn))}
+    enc = nmpc_amd.Encoder(params, device="cuda:0")
+    rng = np.random.default_rng(9)
+    for P in (1, 37):
+        x = f32(rng.uniform(-2, 2, (P, nx))); u = f32(rng.uniform(-2, 2, (P, nu))); xc = f32(rng.uniform(-2, 2, (P, nx)))
+        lam, w = nmpc_amd.quad_nodes("simpson", 10)
+        A, B, C = nmpc_amd.embed(enc, torch.tensor(x), torch.tensor(u), torch.tensor(xc), lam, w)
+        assert A.shape == (P, nx, nx) and B.shape == (P, nx, nu) and C.shape == (P, ny, nx)
+        Ao, Bo, Co = olpv.embed(om, x, u, *olpv.merge_nodes(*olpv.quad_nodes("simpson", 10)), xc=xc)
+        for got, ref in ((A, Ao), (B, Bo), (C, Co)):
+            err = np.abs(got.cpu().numpy().astype(np.float64).reshape(ref.shape) - ref).max()
+            assert err / np.abs(ref).max() < TOL
+    # reference-named entry point on a wide model
+    Jfx, Jfu, Jhx = nmpc_amd.jacobians(enc)
+    A1, B1, C1 = nmpc_amd.lambda_simpson(torch.tensor(x[0]), torch.tensor(u[0]), nx, nu, ny, Jfx, Jfu, Jhx, 10)
+    assert np.abs(A1.cpu().numpy() - Ao[0]).max() / np.abs(Ao).max() < TOL
+    # the synthetic model has no observer net: the closed loop refuses it
+    with pytest.raises(nmpc_amd.NmpcError):
+        nmpc_amd.Controller(enc, nmpc_amd.OutputUnbalancedDisc(dt=0.1), 4, 10, 5, 4, np.eye(nx), 1.0, -1, 1, -1, 1, lam, w)
+
+
+def test_wide_kernel_on_the_disc_model(enc, omodel, monkeypatch):
+    """The general-width kernel is a drop-in for the 64-wide one: same model, same bar."""
+    import subprocess, sys, os
+    code = ("import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests'); import numpy as np, torch, nmpc_amd\n"
+            "from oracle.model import Model; from oracle import lpv as olpv\n"
+            "enc = nmpc_amd.load_system(device='cuda:0'); om = Model.load(); rng = np.random.default_rng(1)\n"
+            "x = rng.uniform(-3, 3, (50, 2)).astype(np.float32).astype(float); u = rng.uniform(-3, 3, (50, 1)).astype(np.float32).astype(float)\n"
+            "lam, w = nmpc_amd.quad_nodes('simpson', 20)\n"
+            "A, B, C = nmpc_amd.embed(enc, torch.tensor(x), torch.tensor(u), torch.tensor(x), lam, w)\n"
+            "Ao, Bo, Co = olpv.embed(om, x, u, *olpv.merge_nodes(*olpv.quad_nodes('simpson', 20)))\n"
+            "e = max(np.abs(g.cpu().numpy().reshape(r.shape) - r).max() / np.abs(r).max() for g, r in ((A, Ao), (B, Bo), (C, Co)))\n"
+            "print('ERR', e); sys.exit(0 if e < 1e-5 else 3)\n")
+    env = dict(os.environ, NMPC_EMBED="wide")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
