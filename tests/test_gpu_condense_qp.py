@@ -141,3 +141,43 @@ def test_mpc_qp_vs_oracle(enc, omodel):
             assert rel(g["Fe"][i], pc["Fe"]) < 1e-12 and rel(g["Le"][i], pc["Le"]) < 1e-13 and rel(g["h"][i], pc["h"]) < 1e-13
             assert rel(g["u"][i], uo) < 1e-10 and abs(g["eps"][i] - eo) < 1e-10 and rel(g["xpred"][i], xpo) < 1e-10
     os.environ.pop("NMPC_MPC_GS", None)
+
+
+def test_open_loop_iteration_wide_model():
+    """One open-loop LPV iteration of the wide synthetic configuration (nx = 8, nu = ny = 1, H = 256, 20
+    lambda-nodes, Nc = 20; 21 QP variables, 82 rows): embedding on the general-width kernel, condensing
+    kernel, batched products for G, F, L, h, batched QP kernel - against the oracle, plans within 1e-5."""
+    import nmpc_amd
+    from oracle.model import Model
+    nx, nu, ny, H, Nc, nb = 8, 1, 1, 256, 20, 6
+    om = Model.synthetic(nx, nu, ny, H, seed=0)
+    for net in (om.fn,):                          # a contraction in the linear branch keeps the prefix products tame
+        net.lin_w = (0.5 * net.lin_w).astype(np.float32).astype(np.float64)
+    om = Model(om.fn, om.hn, None)
+    params = {k: [np.asarray(a, np.float32) for a in n.params()] for k, n in (("fn", om.fn), ("hn", om.hn))}
+    enc = nmpc_amd.Encoder(params, device="cuda:0")
+    rng = np.random.default_rng(2)
+    f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    x0 = f32(rng.standard_normal((nb, nx))); xpred = f32(rng.standard_normal((nb, Nc, nx))); u = f32(rng.uniform(-1, 1, (nb, Nc, 1)))
+    xs = np.concatenate([x0[:, None, :], xpred[:, :-1, :]], 1)
+    lam = (np.arange(20) + 1) / 20.0; w = np.full(20, 0.05)
+    A, B, C = nmpc_amd.embed(enc, torch.tensor(xs), torch.tensor(u), torch.tensor(xpred), lam, w)
+    Q = np.diag(rng.uniform(1, 10, nx)); R = 1.0; rho = 1000.0
+    Xs = np.repeat(0.1 * rng.standard_normal((nb, 1, nx)), Nc, 1).reshape(nb, -1); Us = np.zeros((nb, Nc))
+    ym = rng.uniform(-0.04, 0.04, nb)
+    umin, umax, ymin, ymax = -0.3, 0.3, -0.05, 0.05
+    r = nmpc_amd.mpc_qp(A.double().reshape(nb, Nc * nx, nx), B.double().reshape(nb, Nc * nx, 1), C.double().reshape(nb, Nc, nx),
+                        x0, ym, Xs, Us, om.f0, om.h0, Q, R, rho, umin, umax, ymin, ymax, Nc, nx, want_matrices=True)
+    assert int(r["status"].abs().sum()) == 0
+    Psi = omu.getPsi(Nc, R); Om = omu.getOmega(Nc, Q)
+    D, E, M, c = omu.getDEMc_out([ymin], [ymax], umin, umax, Nc, ny, nu)
+    nact = 0
+    for i in range(nb):
+        Ao, Bo, Co = olpv.embed(om, xs[i], u[i], lam, w, xc=xpred[i])
+        uo, eo, xpo, pc = omq(Ao.reshape(-1, nx), Bo.reshape(-1, 1), Co.reshape(-1, nx), x0[i], ym[i], Xs[i], Us[i], om.f0, om.h0,
+                              Psi, Om, D, E, M, c, Nc, nx, nu, ny, rho)
+        assert np.abs(r["u"][i].cpu().numpy() - uo).max() / max(np.abs(uo).max(), 1e-3) < 1e-5
+        assert np.abs(r["xpred"][i].cpu().numpy() - xpo).max() / np.abs(xpo).max() < 1e-5
+        assert rel(r["Le"][i].cpu().numpy(), pc["Le"]) < 1e-5 and rel(r["h"][i].cpu().numpy(), pc["h"]) < 1e-5
+        nact += int(np.any(pc["Le"] @ np.append(uo, eo) > pc["h"] - 1e-9))
+    assert nact >= 2
