@@ -725,8 +725,14 @@ extern "C" int nmpc_mpc_qp(int nb, int Nc, int nx, const double* list_A, const d
     a.nb = nb; a.nx = nx; a.lA = list_A; a.lB = list_B; a.lC = list_C; a.x0 = x0; a.ymeas = y_meas; a.Xs = Xs; a.Us = Us;
     a.Ge = Ge; a.Fe = Fe; a.Le = Le; a.hv = hv; a.u = u; a.eps = eps; a.xpred = xpred; a.status = status;
     fill_const(a.c, Nc, nx, Q, R, rho, u_min, u_max, y_min, y_max, f0, h0);
-    // diagnostics: NMPC_MPC_STAMPS=<device pointer, hex> receives 8 clock stamps per problem
-    if (const char* e = getenv("NMPC_MPC_STAMPS")) a.stamps = (unsigned long long*)strtoull(e, nullptr, 16);
+    // diagnostics: NMPC_MPC_STAMPS=<device pointer, hex> receives 12 clock stamps per problem
+    if (const char* e = getenv("NMPC_MPC_STAMPS")) {
+        void* p = (void*)strtoull(e, nullptr, 16);
+        hipPointerAttribute_t at;
+        NMPC_REQUIRE(p && hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeDevice,
+                     "nmpc_mpc_qp: NMPC_MPC_STAMPS does not name device memory");
+        a.stamps = (unsigned long long*)p;       // the caller provides 12 * nb words
+    }
     return dispatch_mpc_qp(a, g, (hipStream_t)stream);
 }
 

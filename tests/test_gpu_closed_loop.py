@@ -219,3 +219,27 @@ def test_recorded_closed_loop_of_the_reference(enc):
     idx = recorded_run_windows(r[1], 450)
     assert np.abs(y[idx] - q[idx]).max() < 5e-3 and np.abs(u[idx] - w[idx]).max() < 2e-2
     assert np.median(np.abs(y - q)) < 6e-3
+
+
+def test_noisy_converged_configuration_at_scale(enc, omodel):
+    """sigma_n = 0.014 (SNR 30), LPV passes iterated to convergence (tol 1e-5, cap 10), 2048 controllers
+    (one GPU's share of the 16384-controller configuration): the first controllers agree with the oracle
+    on the same noise, and the batch as a whole is deterministic and tracks."""
+    import nmpc_amd
+    B, Nsim, Nc = 2048, 30, 10
+    refs = np.stack([random_level_reference(Nsim + Nc, [10, 15], [-1, 1], np.random.default_rng(1234 + b)) for b in range(B)])
+    noise = 0.014 * np.random.default_rng(99).standard_normal((Nsim, B))
+    plant = nmpc_amd.OutputUnbalancedDisc(dt=0.1, sigma_n=[0.014])
+    run = lambda: nmpc_amd.output_NMPC_linear(plant, enc, -4, 4, [-1.2], [1.2], np.zeros(2), Q, 1.0, 0.1, 0.05, 20, refs, Nc=Nc,
+                                              Nsim=Nsim, max_iterations=10, tol=1e-5, noise=noise)
+    a = run(); b = run()
+    for i in (0, 1, 6, 8):
+        assert torch.equal(a[i], b[i]), i
+    lp = a[6].cpu().numpy()
+    assert lp.min() >= 1 and lp.max() <= 10 and lp.mean() > 2.0          # convergence to 1e-5 takes several passes
+    for c in range(3):
+        o = output_nmpc_linear(omodel, -4, 4, [-1.2], [1.2], np.zeros(2), Q, 1.0, 0.1, 20, refs[c], Nc=Nc, Nsim=Nsim,
+                               max_iterations=10, tol=1e-5, noise=noise[:, c])
+        assert np.abs(a[8][c].cpu().numpy() - o["y_log"]).max() < 1e-4 and np.abs(a[1][c].cpu().numpy() - o["u_log"]).max() < 1e-4
+    y = a[8].cpu().numpy()
+    assert np.median(np.abs(y[:, 10:Nsim + 1:5] - refs[:, 9:Nsim:5])) < 0.1
