@@ -248,6 +248,9 @@ def main():
                                       "other slices' kernels; the kernel is VALU/issue-bound (exp2, rcp, splits), "
                                       "the matrix pipe is about 40% busy",
                          "achieved_isolated": iso, "frac_isolated": iso / peak,
+                         "achieved_over_wall": FLOPS_PER_POINT * NC * passes / elapsed_max / 1e12,
+                         "over_wall_note": "all embedding flops of this rank / wall time of the timed region "
+                                           "(QP and plant kernels included in the time)",
                          "frac_of_f32_mfma_peak_isolated": iso / 157.3,
                          "traffic_unit": "bytes per launch (HBM, PMC)", "traffic_source": traffic_src,
                          "kernel": "embed_kernel", "launches": n_launch,
