@@ -143,6 +143,97 @@ __device__ __forceinline__ double rsqrt_d(double d) {
     return r;
 }
 
+// Whole-wave (GS = 64) Cholesky for any nn <= 64 with lane i owning row i of M in LDS: the pivot
+// column travels through v_readlane and every lane touches only its own row, so the factorisation
+// needs no barrier.  Rows below the pivot take the symmetric update over their whole tail (the part
+// right of the diagonal is never read again), which keeps the chunked inner loop free of per-element
+// predicates.
+__device__ __forceinline__ bool chol_rows_lds(double* M, int nn, int ld, double* invd) {
+    constexpr int UNR = 8;
+    const int lane = threadIdx.x & 63;
+    if (nn <= 0) return true;
+    const bool own = lane < nn;
+    double* row = M + (own ? lane : nn - 1) * ld;   // idle lanes read row nn-1 and never store
+    for (int j = 0; j < nn; ++j) {
+        double lij = row[j];
+        const double d = readlane_d(lij, j);
+        if (!(d > 0.0)) return false;               // wave-uniform
+        const double inv = rsqrt_d(d);
+        lij *= inv;
+        if (own && lane >= j) row[j] = lij;
+        if (lane == 0) invd[j] = inv;
+        int c0 = j + 1;
+        for (; c0 + UNR <= nn; c0 += UNR) {
+            double m[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) m[u] = row[c0 + u];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) m[u] = fma(-lij, readlane_d(lij, c0 + u), m[u]);
+            if (own && lane > j) {
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) row[c0 + u] = m[u];
+            }
+        }
+        for (; c0 < nn; ++c0) {
+            const double m = fma(-lij, readlane_d(lij, c0), row[c0]);
+            if (own && lane > j) row[c0] = m;
+        }
+    }
+    return true;
+}
+
+// Whole-wave forward substitution of every column of Nt and of xt by the factor in Lm (any n <= 64):
+// column <- L^-1 (-column).  Constraint columns: one per lane and slot, all slots advancing together
+// so that one broadcast read of L[k][l] serves them all (lanes past the last column read in-bounds
+// neighbours and store nothing).  xt: lane k owns component k and the solved entries travel through
+// v_readlane.  Needs 64 * MPL >= mt; reads up to 64 * MPL - mt doubles past the end of Nt, which the
+// work area carved behind it (mt + 8 n doubles, n > 16 on this path) covers for MPL in {1, 2, 4}.
+template <int MPL>
+__device__ __forceinline__ void transform_cols_lds(const double* Lm, double* Nt, double* xt, const double* invd, int n, int mt) {
+    constexpr int UNR = 4;
+    const int lane = threadIdx.x & 63;
+    for (int k = 0; k < n; ++k) {
+        double v[MPL];
+#pragma unroll
+        for (int sl = 0; sl < MPL; ++sl) v[sl] = -Nt[k * mt + lane + 64 * sl];
+        int l0 = 0;
+        for (; l0 + UNR <= k; l0 += UNR) {
+            double lv[UNR], y[UNR][MPL];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                lv[u] = Lm[k * n + l0 + u];
+#pragma unroll
+                for (int sl = 0; sl < MPL; ++sl) y[u][sl] = Nt[(l0 + u) * mt + lane + 64 * sl];
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                for (int sl = 0; sl < MPL; ++sl) v[sl] = fma(-lv[u], y[u][sl], v[sl]);
+        }
+        for (; l0 < k; ++l0) {
+            const double lv = Lm[k * n + l0];
+#pragma unroll
+            for (int sl = 0; sl < MPL; ++sl) v[sl] = fma(-lv, Nt[l0 * mt + lane + 64 * sl], v[sl]);
+        }
+        const double ik = invd[k];
+#pragma unroll
+        for (int sl = 0; sl < MPL; ++sl)
+            if (lane + 64 * sl < mt) Nt[k * mt + lane + 64 * sl] = v[sl] * ik;
+    }
+    const int kr = lane < n ? lane : n - 1;
+    double v = -xt[kr], res = 0.0;
+    const double invl = invd[kr];
+    double lnext = Lm[kr * n];
+    for (int l = 0; l < n; ++l) {
+        const double lcur = lnext;
+        if (l + 1 < n) lnext = Lm[kr * n + l + 1];
+        const double yl = readlane_d(v, l) * readlane_d(invl, l);
+        if (lane == l) res = yl;
+        if (lane > l) v = fma(-lcur, yl, v);
+    }
+    if (lane < n) xt[lane] = res;
+}
+
 // Whole-wave (GS = 64) Cholesky and transform for n <= NMAX with lane i holding row i of the
 // matrix in registers: the pivot column travels through v_readlane (an SGPR broadcast), so no LDS
 // round trip or barrier sits on the critical path.  On exit Lm holds L (row-major), invd the
@@ -244,6 +335,14 @@ __device__ __forceinline__ int gi_solve(int n, int mt, int meq, QPWork& w, doubl
             if (iters_out) *iters_out = 0;
             return 3;
         }
+    } else if constexpr (GS == 64) {
+        if (!chol_rows_lds(Lm, n, n, w.invdL)) {
+            if (iters_out) *iters_out = 0;
+            return 3;
+        }
+        if (stamp && gl == 0) stamp[0] = __builtin_amdgcn_s_memtime();
+        g_sync();
+        transform_cols_lds<MPL>(Lm, Nt, xt, w.invdL, n, mt);
     } else {
         if (!g_chol<GS>(Lm, n, n, w.invdL, gl)) {
             if (iters_out) *iters_out = 0;
@@ -412,21 +511,26 @@ __device__ __forceinline__ int gi_solve(int n, int mt, int meq, QPWork& w, doubl
                     double a = Nt[kr * mt + p];
                     for (int j = 0; j < q; ++j)
                         a = fma(-Nt[kr * mt + __builtin_amdgcn_readlane(wj, j)], readlane_d(rj, j), a);
+                    // all row slots advance together: a chunk keeps UNR * MPL loads in flight
+                    double dot[MPL];
+                    int ic[MPL];
 #pragma unroll
                     for (int sl = 0; sl < MPL; ++sl) {
-                        const int i = gl + sl * GS;
-                        const int ic = i < mt ? i : mt - 1;
-                        double dot = 0.0;
-                        for (int k0 = 0; k0 < n; k0 += UNR) {
-#pragma unroll
-                            for (int u = 0; u < UNR; ++u) {
-                                const int k = k0 + u, kk = k < n ? k : n - 1;
-                                const double nk = Nt[kk * mt + ic];
-                                dot = fma(k < n ? nk : 0.0, readlane_d(a, kk), dot);
-                            }
-                        }
-                        if (i < mt) s[sl] = fma(t, dot, s[sl]);
+                        dot[sl] = 0.0;
+                        ic[sl] = gl + sl * GS < mt ? gl + sl * GS : mt - 1;
                     }
+                    for (int k0 = 0; k0 < n; k0 += UNR) {
+#pragma unroll
+                        for (int u = 0; u < UNR; ++u) {
+                            const int k = k0 + u, kk = k < n ? k : n - 1;
+                            const double ak = k < n ? readlane_d(a, kk) : 0.0;
+#pragma unroll
+                            for (int sl = 0; sl < MPL; ++sl) dot[sl] = fma(Nt[kk * mt + ic[sl]], ak, dot[sl]);
+                        }
+                    }
+#pragma unroll
+                    for (int sl = 0; sl < MPL; ++sl)
+                        if (gl + sl * GS < mt) s[sl] = fma(t, dot[sl], s[sl]);
                 } else {
                     g_sync();
                     if (gl < q) { w.rW[gl] = rj; w.Wl[gl] = wj; }
@@ -478,15 +582,35 @@ __device__ __forceinline__ int gi_solve(int n, int mt, int meq, QPWork& w, doubl
                 g_sync();
                 if (gl < q) w.Wl[gl] = wj;
                 g_sync();
-                if (gl < q)
-                    for (int b = 0; b <= gl; ++b) {
-                        const int wb = w.Wl[b];
-                        double a = 0.0;
-                        for (int k = 0; k < n; ++k) a += Nt[k * mt + wj] * Nt[k * mt + wb];
-                        Lw[gl * n + b] = a;
-                    }
-                g_sync();
-                if (!g_chol<GS>(Lw, q, n, w.invdW, gl)) { status = 2; break; }
+                if constexpr (FAST) {
+                    if (gl < q)
+                        for (int b = 0; b <= gl; ++b) {
+                            const int wb = w.Wl[b];
+                            double a = 0.0;
+                            for (int k0 = 0; k0 < n; k0 += UNR) {
+#pragma unroll
+                                for (int u = 0; u < UNR; ++u) {
+                                    const int k = k0 + u, kk = k < n ? k : n - 1;
+                                    const double x = Nt[kk * mt + wj], y = Nt[kk * mt + wb];
+                                    a = fma(k < n ? x : 0.0, y, a);
+                                }
+                            }
+                            Lw[gl * n + b] = a;
+                        }
+                    g_sync();
+                    if (!chol_rows_lds(Lw, q, n, w.invdW)) { status = 2; break; }
+                    g_sync();
+                } else {
+                    if (gl < q)
+                        for (int b = 0; b <= gl; ++b) {
+                            const int wb = w.Wl[b];
+                            double a = 0.0;
+                            for (int k = 0; k < n; ++k) a += Nt[k * mt + wj] * Nt[k * mt + wb];
+                            Lw[gl * n + b] = a;
+                        }
+                    g_sync();
+                    if (!g_chol<GS>(Lw, q, n, w.invdW, gl)) { status = 2; break; }
+                }
                 double sv = 0.0;
 #pragma unroll
                 for (int sl = 0; sl < MPL; ++sl) if (sl == p / GS) sv = s[sl];
