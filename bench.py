@@ -258,7 +258,7 @@ def main():
                          "flops_per_launch": embed_flops / max(n_launch, 1)},
         }
         res["p50_step_latency_ms"] = p50_latency         # 40 single steps, each host-synchronised
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # host baseline: single-GPU runs only
             nc, ns = args.cpu_controllers, min(args.cpu_steps, nsim)
             v = cpu_baseline(nc, ns, refs)
             res["cpu_baseline"] = {"value": v, "unit": "controller-steps/s", "cores": 1, "kind": "port",
