@@ -630,7 +630,7 @@ static int pick_gs(int Nc) {
 struct MpcGeom { int GS, gpb, mpl; size_t lds; };
 static int mpc_geom(int Nc, int nx, int mode, int slack, MpcGeom& g) {
     NMPC_REQUIRE(Nc >= 1 && Nc + 1 <= 64, "horizon Nc=%d unsupported (1..63)", Nc);
-    NMPC_REQUIRE(nx >= 1 && nx <= 4, "nx=%d unsupported by the MPC kernels (1..4)", nx);
+    NMPC_REQUIRE(nx == 2 || nx == 3, "nx=%d unsupported by the fused MPC kernels (2 or 3)", nx);
     g.GS = pick_gs(Nc);
     const int n = mpc_nvar(Nc, slack), mt = mpc_nrows(Nc, nx, mode);
     NMPC_REQUIRE(mt <= 4 * 64, "horizon Nc=%d gives %d constraint rows (at most 256)", Nc, mt);

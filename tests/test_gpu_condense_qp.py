@@ -143,13 +143,15 @@ def test_mpc_qp_vs_oracle(enc, omodel):
     os.environ.pop("NMPC_MPC_GS", None)
 
 
-def test_open_loop_iteration_wide_model():
+@pytest.mark.parametrize("nx,H,Nc", [(8, 256, 20), (4, 64, 10)])
+def test_open_loop_iteration_wide_model(nx, H, Nc):
     """One open-loop LPV iteration of the wide synthetic configuration (nx = 8, nu = ny = 1, H = 256, 20
-    lambda-nodes, Nc = 20; 21 QP variables, 82 rows): embedding on the general-width kernel, condensing
-    kernel, batched products for G, F, L, h, batched QP kernel - against the oracle, plans within 1e-5."""
+    lambda-nodes, Nc = 20; 21 QP variables, 82 rows) and of the shape of the reference's LTI example (nx = 4,
+    H = 64, LTI.ipynb cell 5): embedding on the general-width kernel, condensing kernel, batched products
+    for G, F, L, h, batched QP kernel - against the oracle, plans within 1e-5."""
     import nmpc_amd
     from oracle.model import Model
-    nx, nu, ny, H, Nc, nb = 8, 1, 1, 256, 20, 6
+    nu, ny, nb = 1, 1, 6
     om = Model.synthetic(nx, nu, ny, H, seed=0)
     for net in (om.fn,):                          # a contraction in the linear branch keeps the prefix products tame
         net.lin_w = (0.5 * net.lin_w).astype(np.float32).astype(np.float64)
