@@ -200,13 +200,12 @@ __device__ __forceinline__ void embed_tile(const float* __restrict__ pack, float
 // Split-fp16 variant.  On gfx950 the fp32-input MFMA issues at the fp32 VECTOR rate and does not
 // overlap with VALU work (PMC: matrix-busy + VALU-busy cycles = kernel cycles, zero co-execution),
 // so the fp32 kernel above runs at (MFMA + VALU) time.  Here every fp32 operand x is written as
-//     x = xh + 2^-11 xl',   xh = x with its significand cut to 11 bits (exact in fp16),
-//                           xl' = fp16((x - xh) 2^11)                      (22 bits in total)
-// and a product W x is evaluated as  Wh xh + 2^-11 (Wh xl' + Wl' xh)  with three
-// v_mfma_f32_16x16x32_f16 (fp16 products are exact in the fp32 accumulator; the dropped Wl xl term
-// is 2^-22 relative).  These run on the matrix pipe at 16x the fp32 rate and concurrently with the
-// VALU, which leaves the kernel bound by the activation (v_exp/v_rcp) work.  The low parts carry a
-// 2^11 scale so that they stay in fp16's normal range; they accumulate in their own register set.
+//     x = xh + xl,   xh = x with its significand cut to 11 bits (exact in fp16),
+//                    xl = fp16(x - xh)   (unscaled, mostly subnormal: gfx950 MFMAs honour subnormals)
+// and a product W x is evaluated as  Wh xh + Wh xl + Wl xh  with three v_mfma_f32_16x16x32_f16 into
+// ONE fp32 accumulator (fp16 products are exact in fp32; the dropped Wl xl term is 2^-22 relative).
+// These run on the matrix pipe at 16x the fp32 rate, which leaves the kernel bound by instruction
+// issue: the activation math (v_exp/v_rcp), the splits and the MFMA issue slots themselves.
 // Unit numbering, accumulator->operand reuse and the hoisted W0 contraction are as in embed_tile:
 // element j of k-step ks of a B fragment is unit s = 8 ks + j = 4 T + r of the accumulator tiles.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
