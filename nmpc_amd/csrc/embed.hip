@@ -22,6 +22,7 @@
 #include "embed.h"
 
 #include <cstdlib>
+#include <algorithm>
 #include <string>
 
 namespace nmpc {
@@ -305,9 +306,20 @@ __device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, fl
         b0[s] = rec[0];
         b2[s >> 2][s & 3] = rec[1];
     }
+    // The node weight is applied once per run of equal weights (the host orders the nodes by weight):
+    // q holds the sum in units of the current weight and is rescaled when the weight changes.
+    float wcur = n0 < n1 ? nt.w[n0] : 0.0f;
     for (int node = n0; node < n1; ++node) {
         const float lam = nt.lam[node];
-        const float w4 = 4.0f * nt.w[node];
+        const float wn = nt.w[node];
+        if (wn != wcur) {                          // wave-uniform, rare
+            const float sc = wcur / wn;
+#pragma unroll
+            for (int c = 0; c < NOUT; ++c)
+#pragma unroll
+                for (int s = 0; s < 16; ++s) q[c][s] *= sc;
+            wcur = wn;
+        }
         int lo = lane;
         asm volatile("" : "+v"(lo));
         float t1[16], wd1[16];
@@ -316,7 +328,7 @@ __device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, fl
             const float a = fmaf(lam, g[s], b0[s]);
             const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-a));
             t1[s] = fmaf(2.0f, r, -1.0f);
-            wd1[s] = w4 * fmaf(-r, r, r);          // w * (1 - t1^2)
+            wd1[s] = fmaf(-r, r, r);               // (1 - t1^2) / 4
         }
         f16x8 BH[2], BL[2];
         split16(t1, BH, BL);
@@ -371,13 +383,14 @@ __device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, fl
 #pragma unroll
             for (int j = 0; j < NIN; ++j) pj[c][j] = fmaf(q[c][s], w0[j], pj[c][j]);
     }
+    const float wlast = 4.0f * wcur;               // the weight of the last run and the 4 of (1 - t1^2) / 4
     float* red = lds + L_RED;
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < NOUT; ++c)
 #pragma unroll
         for (int j = 0; j < NIN; ++j) {
-            float v = pj[c][j];
+            float v = wlast * pj[c][j];
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
             if (hq == 0) red[(wave * EMBED_TILE + n) * (NOUT * NIN) + c * NIN + j] = v;
@@ -453,7 +466,17 @@ int embed_launch(const ModelDev& m, EmbedArgs a, const NodeTable& nodes, hipStre
     for (int i = 0; i < nodes.n; ++i) {
         nt.w_sum += nodes.w[i];
         if (nodes.lam[i] == 0.0f) { nt.w_zero += nodes.w[i]; continue; }
+        if (nodes.w[i] == 0.0f) continue;          // contributes nothing
         nt.lam[nt.n] = nodes.lam[i]; nt.w[nt.n] = nodes.w[i]; ++nt.n;
+    }
+    {   // equal weights next to each other (the sum over nodes does not depend on their order): the
+        // split-fp16 kernel applies a weight once per run of equal weights
+        int idx[NMPC_MAX_NODES];
+        for (int i = 0; i < nt.n; ++i) idx[i] = i;
+        std::stable_sort(idx, idx + nt.n, [&](int a, int b) { return nt.w[a] > nt.w[b]; });
+        NodeTable sorted = nt;
+        for (int i = 0; i < nt.n; ++i) { sorted.lam[i] = nt.lam[idx[i]]; sorted.w[i] = nt.w[idx[i]]; }
+        nt = sorted;
     }
     NMPC_REQUIRE(a.npts >= 0, "embed: negative point count");
     if (a.npts == 0) return 0;
