@@ -322,16 +322,16 @@ __device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, fl
         }
         int lo = lane;
         asm volatile("" : "+v"(lo));
-        float t1[16], wd1[16];
+        float r1[16], wd1[16];                     // r1 = (1 + t1) / 2 is the operand of the forward product
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const float a = fmaf(lam, g[s], b0[s]);
             const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-a));
-            t1[s] = fmaf(2.0f, r, -1.0f);
+            r1[s] = r;
             wd1[s] = fmaf(-r, r, r);               // (1 - t1^2) / 4
         }
         f16x8 BH[2], BL[2];
-        split16(t1, BH, BL);
+        split16(r1, BH, BL);
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
         f32x4 acc[4];
 #pragma unroll

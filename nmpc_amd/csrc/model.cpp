@@ -100,10 +100,18 @@ static bool pack_net_h2(const float* const* p, int n_in, int n_out, std::vector<
                 for (int j = 0; j < 8; ++j) {
                     const int hq = lane >> 4, r = lane & 15;
                     const int k = 16 * (2 * ks + (j >> 2)) + 4 * hq + (j & 3);
-                    put(PK_WF, T, ks, lane, j, c2 * (double)w2[(16 * T + r) * HID + k]);
+                    put(PK_WF, T, ks, lane, j, 2.0 * c2 * (double)w2[(16 * T + r) * HID + k]);
                     for (int c = 0; c < n_out; ++c)
                         put(PK_WR + 4096 * c, T, ks, lane, j, (double)w2[k * HID + 16 * T + r] * 4.0 * (double)w4[c * HID + k]);
                 }
+    // The forward product takes r = (1 + t1) / 2 = 1 / (1 + 2^-a) as its operand instead of t1 = tanh:
+    // W2 t1 + b2 = (2 W2) r + (b2 - W2 1); the fragments above carry the 2, the bias the constant.
+    const float* b2 = p[5];
+    for (int k = 0; k < HID; ++k) {
+        double a = b2[k];
+        for (int i = 0; i < HID; ++i) a -= (double)w2[k * HID + i];
+        out[PK_REC1 + 4 * k + 1] = (float)(c2 * a);
+    }
     for (int i = 0; i <= n_out; ++i)
         if (wmax[i] < 1.0 / 64.0) ok = false;
     return ok;
