@@ -10,7 +10,7 @@ import torch
 from oracle import lpv as olpv
 from oracle.nmpc import output_nmpc_linear, target_selector
 from oracle.plant import random_level_reference
-from conftest import disc_setup, GOLDEN
+from conftest import disc_setup, padded_disc_model, GOLDEN
 
 pytestmark = pytest.mark.gpu
 Q = np.diag([1000.0, 10.0])
@@ -51,13 +51,13 @@ def run_both(enc, omodel, refs, Nsim, noise=None, tol=1e-1, max_it=4, sigma=0.0)
     return orc, out, ctrl
 
 
-def check_parity(orc, out, ctrl, Nsim, traj_tol=1e-4, min_same=0.99):
+def check_parity(orc, out, ctrl, Nsim, traj_tol=1e-4, min_same=0.99, nx=2):
     B = len(orc)
     x_log, u_log, e_log, comp_t, t, runtime, lpvc, ct, y_log, y_est, Xs, Us = out
     st = lambda k: np.stack([o[k] for o in orc])
     assert np.abs(y_log.cpu().numpy() - st("y_log")).max() < traj_tol
     assert np.abs(u_log.cpu().numpy() - st("u_log")).max() < traj_tol
-    assert np.abs(x_log.cpu().numpy().reshape(B, Nsim + 1, 2) - st("x_log")).max() < traj_tol
+    assert np.abs(x_log.cpu().numpy().reshape(B, Nsim + 1, nx) - st("x_log")).max() < traj_tol
     assert np.abs(y_est.cpu().numpy() - st("y_est_log")).max() < traj_tol
     assert np.abs(e_log[:, 0].cpu().numpy() - st("e_log")).max() < traj_tol
     plan, plano = ctrl.logs["plan_log"].cpu().numpy(), st("plan_log")
@@ -243,3 +243,37 @@ def test_noisy_converged_configuration_at_scale(enc, omodel):
         assert np.abs(a[8][c].cpu().numpy() - o["y_log"]).max() < 1e-4 and np.abs(a[1][c].cpu().numpy() - o["u_log"]).max() < 1e-4
     y = a[8].cpu().numpy()
     assert np.median(np.abs(y[:, 10:Nsim + 1:5] - refs[:, 9:Nsim:5])) < 0.1
+
+
+def test_closed_loop_three_state_model(omodel):
+    """nx = 3 instantiations of every kernel on the path (64-wide embedding, fused condense + QP, plant /
+    observer step, target selector): the trained disc model padded with a third, weakly coupled state,
+    6 controllers, noisy measurement, up to 4 LPV passes, against the oracle."""
+    import nmpc_amd
+    om3 = padded_disc_model(omodel)
+    params = {k: [np.asarray(a, np.float32) for a in n.params()] for k, n in (("fn", om3.fn), ("hn", om3.hn), ("enc", om3.enc))}
+    norm = nmpc_amd.Norm(om3.u0, om3.ustd, om3.y0, om3.ystd)
+    enc3 = nmpc_amd.Encoder(params, norm=norm, na=om3.na, nb=om3.nb, device="cuda:0")
+    # embedding alone first (narrow nx = 3 kernel)
+    rng = np.random.default_rng(4)
+    f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    P = 150
+    x = f32(rng.uniform(-2, 2, (P, 3))); u = f32(rng.uniform(-2, 2, (P, 1))); xc = f32(rng.uniform(-2, 2, (P, 3)))
+    lam, w = nmpc_amd.quad_nodes("simpson", 20)
+    A, Bm, C = nmpc_amd.embed(enc3, torch.tensor(x), torch.tensor(u), torch.tensor(xc), lam, w)
+    Ao, Bo, Co = olpv.embed(om3, x, u, *olpv.merge_nodes(*olpv.quad_nodes("simpson", 20)), xc=xc)
+    for got, ref in ((A, Ao), (Bm, Bo), (C, Co)):
+        assert np.abs(got.cpu().numpy().astype(np.float64).reshape(ref.shape) - ref).max() / np.abs(ref).max() < 1e-5
+    # closed loop
+    Nsim, B, Nc = 40, 6, 10
+    Q3 = np.diag([1000.0, 10.0, 1.0])
+    refs = np.stack([random_level_reference(Nsim + Nc, [10, 15], [-1, 1], np.random.default_rng(77 + b)) for b in range(B)])
+    noise = 0.014 * np.random.default_rng(8).standard_normal((Nsim, B))
+    orc = [output_nmpc_linear(om3, -4, 4, [-1.2], [1.2], np.zeros(3), Q3, 1.0, 0.1, 20, refs[b], Nc=Nc, Nsim=Nsim,
+                              max_iterations=4, tol=1e-1, noise=noise[:, b]) for b in range(B)]
+    plant = nmpc_amd.OutputUnbalancedDisc(dt=0.1, sigma_n=[0.014])
+    out, ctrl = nmpc_amd.output_NMPC_linear(plant, enc3, -4, 4, [-1.2], [1.2], np.zeros(3), Q3, 1.0, 0.1, 0.05, 20, refs, Nc=Nc,
+                                            Nsim=Nsim, max_iterations=4, tol=1e-1, noise=noise, return_controller=True)
+    check_parity(orc, out, ctrl, Nsim, nx=3)
+    y = out[8].cpu().numpy()
+    assert np.median(np.abs(y[:, 1:] - refs[:, :Nsim])) < 0.1        # the loop still tracks
