@@ -70,11 +70,12 @@ def check_parity(orc, out, ctrl, Nsim, traj_tol=1e-4, min_same=0.99, nx=2):
     assert np.abs(Xs.cpu().numpy() - st("Xs")).max() < 1e-5 and np.abs(Us.cpu().numpy() - st("Us")).max() < 1e-5
 
 
-@pytest.mark.parametrize("Nc,nb", [(10, 64), (7, 9), (50, 10)])
+@pytest.mark.parametrize("Nc,nb", [(10, 64), (7, 9), (15, 9), (16, 9), (20, 9), (50, 10)])
 def test_single_pass_plan_same_inputs(enc, omodel, Nc, nb):
     """One LPV pass from identical inputs: embedding at the scheduling points, then the condensed QP;
     the planned control sequence must match the fp64 oracle within 1e-5 relative.  Nc = 50 is the
-    long-horizon configuration (51 variables, 202 constraint rows)."""
+    long-horizon configuration (51 variables, 202 constraint rows); 15 / 16 straddle the switch from the
+    register-resident to the LDS-resident factorisation, 20 uses two constraint rows per lane."""
     import nmpc_amd
     from oracle import mpcutil as omu
     from oracle.nmpc import mpc_qp as omq
