@@ -102,6 +102,14 @@ def test_qp_special_cases():
         assert int(status) == 0
         assert np.abs(zt.cpu().numpy() - osolve(Pm, qv, Gm, hv, A, b)).max() < 1e-10
         assert np.abs(A @ zt.cpu().numpy() - b).max() < 1e-11
+    # the same beyond 16 variables (LDS-resident factorisation), two rows per lane
+    for t in range(6):
+        n = 24; M = rng.standard_normal((n, n)); Pm = M @ M.T + 0.1 * np.eye(n); qv = rng.standard_normal(n)
+        Gm = rng.standard_normal((70, n)); hv = rng.uniform(0.1, 1, 70); A = rng.standard_normal((3, n)); b = 0.1 * rng.standard_normal(3)
+        zt, lam, status, _ = nmpc_amd.solve_qp(Pm, qv, Gm, hv, A, b, return_info=True)
+        assert int(status) == 0
+        assert np.abs(zt.cpu().numpy() - osolve(Pm, qv, Gm, hv, A, b)).max() < 1e-9
+        assert np.abs(A @ zt.cpu().numpy() - b).max() < 1e-10
     # infeasible and indefinite problems are reported, not silently "solved"
     Pm = np.eye(3); qv = np.ones(3)
     _, _, status, _ = nmpc_amd.solve_qp(Pm, qv, np.array([[1.0, 0, 0], [-1.0, 0, 0]]), np.array([-1.0, -1.0]), return_info=True)
