@@ -630,7 +630,7 @@ static int pick_gs(int Nc) {
 struct MpcGeom { int GS, gpb, mpl; size_t lds; };
 static int mpc_geom(int Nc, int nx, int mode, int slack, MpcGeom& g) {
     NMPC_REQUIRE(Nc >= 1 && Nc + 1 <= 64, "horizon Nc=%d unsupported (1..63)", Nc);
-    NMPC_REQUIRE(nx == 2 || nx == 3, "nx=%d unsupported by the fused MPC kernels (2 or 3)", nx);
+    NMPC_REQUIRE(nx >= 2 && nx <= 4, "nx=%d unsupported by the fused MPC kernels (2..4)", nx);
     g.GS = pick_gs(Nc);
     const int n = mpc_nvar(Nc, slack), mt = mpc_nrows(Nc, nx, mode);
     NMPC_REQUIRE(mt <= 4 * 64, "horizon Nc=%d gives %d constraint rows (at most 256)", Nc, mt);
@@ -690,6 +690,7 @@ static int dispatch_mpc_qp(const MpcQpArgs& a, const MpcGeom& g, hipStream_t s) 
     if (a.nx == 2 && a.c.Nc == 10 && a.c.mode == 0 && a.c.slack && g.GS == 64 && g.mpl <= 1) return launch_mpc_qp<64, 1, 2, 10>(a, g, s);
     if (a.nx == 2) { NMPC_GEOM_SWITCH(launch_mpc_qp, 2, g, a, g, s) }
     if (a.nx == 3) { NMPC_GEOM_SWITCH(launch_mpc_qp, 3, g, a, g, s) }
+    if (a.nx == 4) { NMPC_GEOM_SWITCH(launch_mpc_qp, 4, g, a, g, s) }
     set_error("nmpc_mpc_qp: no kernel for nx=%d GS=%d rows/lane=%d", a.nx, g.GS, g.mpl);
     return 1;
 }
@@ -698,6 +699,7 @@ static int dispatch_mpc_solve(const CtrlDev& d, const RunPtrs& rp, int it, int k
     if (d.nx == 2 && d.Nc == 10 && d.c.mode == 0 && d.c.slack && g.GS == 64 && g.mpl <= 1) return launch_mpc_solve<64, 1, 2, 10>(d, rp, it, k, g, s);
     if (d.nx == 2) { NMPC_GEOM_SWITCH(launch_mpc_solve, 2, g, d, rp, it, k, g, s) }
     if (d.nx == 3) { NMPC_GEOM_SWITCH(launch_mpc_solve, 3, g, d, rp, it, k, g, s) }
+    if (d.nx == 4) { NMPC_GEOM_SWITCH(launch_mpc_solve, 4, g, d, rp, it, k, g, s) }
     set_error("nmpc_ctrl_run: no kernel for nx=%d GS=%d rows/lane=%d", d.nx, g.GS, g.mpl);
     return 1;
 }
@@ -781,7 +783,7 @@ extern "C" int nmpc_ctrl_create(nmpc_ctrl** out, const nmpc_model* m, const nmpc
     NMPC_REQUIRE(m->d.nu == 1 && m->d.ny == 1, "nmpc_ctrl_create: closed loop needs nu = ny = 1 (as the reference)");
     const int mode = cfg->mode;
     NMPC_REQUIRE(mode == 0 || mode == 1, "nmpc_ctrl_create: mode %d unknown (0 output feedback, 1 state feedback)", mode);
-    NMPC_REQUIRE(mode == 1 || (m->d.enc && m->d.n_enc_in <= MAX_HIST), "nmpc_ctrl_create: model has no observer net");
+    NMPC_REQUIRE(mode == 1 || (m->d.enc && m->d.hplain && m->d.n_enc_in <= MAX_HIST), "nmpc_ctrl_create: model has no observer net");
     NMPC_REQUIRE(mode == 0 || m->d.nx == 2, "nmpc_ctrl_create: state feedback drives the two-state disc plant (nx = 2)");
     NMPC_REQUIRE(cfg->Nc * m->d.nx <= 128, "nmpc_ctrl_create: Nc*nx=%d exceeds 128", cfg->Nc * m->d.nx);
     NMPC_REQUIRE(cfg->batch >= 1 && cfg->max_iterations >= 1 && cfg->max_iterations <= 64 && cfg->n_sim >= 1,
@@ -887,6 +889,7 @@ extern "C" int nmpc_ctrl_reset(nmpc_ctrl* c, const double* x0n, double u0n, cons
     const int threads = 128, grid = (c->d.B + threads - 1) / threads;
     if (c->d.nx == 2) hipLaunchKernelGGL((reset_kernel<2>), dim3(grid), dim3(threads), 0, (hipStream_t)stream, c->d, u0n, x0[0], x0[1], x0[2], x0[3], pw, pth);
     else if (c->d.nx == 3) hipLaunchKernelGGL((reset_kernel<3>), dim3(grid), dim3(threads), 0, (hipStream_t)stream, c->d, u0n, x0[0], x0[1], x0[2], x0[3], pw, pth);
+    else if (c->d.nx == 4) hipLaunchKernelGGL((reset_kernel<4>), dim3(grid), dim3(threads), 0, (hipStream_t)stream, c->d, u0n, x0[0], x0[1], x0[2], x0[3], pw, pth);
     else { set_error("nmpc_ctrl_reset: nx=%d unsupported", c->d.nx); return 1; }
     NMPC_HIP_CHECK(hipGetLastError());
     return 0;
@@ -946,6 +949,7 @@ extern "C" int nmpc_ctrl_run(nmpc_ctrl* c, int k0, int nsteps, const double* Xs,
             if (d.c.mode == 1) hipLaunchKernelGGL((plant_state_kernel<2>), dim3((d.B + 127) / 128), dim3(128), 0, s, d, rp, k);
             else if (d.nx == 2) hipLaunchKernelGGL((plant_kernel<2>), dim3(grid), dim3(threads), 0, s, d, rp, k);
             else if (d.nx == 3) hipLaunchKernelGGL((plant_kernel<3>), dim3(grid), dim3(threads), 0, s, d, rp, k);
+            else if (d.nx == 4) hipLaunchKernelGGL((plant_kernel<4>), dim3(grid), dim3(threads), 0, s, d, rp, k);
             else { set_error("nmpc_ctrl_run: nx=%d unsupported", d.nx); return 1; }
             NMPC_HIP_CHECK(hipGetLastError());
             prof_end(c, on, s, pr);

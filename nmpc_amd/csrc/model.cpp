@@ -234,8 +234,24 @@ extern "C" int nmpc_model_create(nmpc_model** out, int nx, int nu, int ny, int h
     }
     eval_net_at_zero(fn, nx + nu, nx, hidden, m->d.f0);
     eval_net_at_zero(hn, nx, ny, hidden, m->d.h0);
-    if (!narrow) {           // no 64-wide packs, no plain nets for the closed-loop observer
-        NMPC_REQUIRE(!enc, "nmpc_model_create: an observer net needs hidden = 64, nu = ny = 1, nx = 2 or 3");
+    // plain-layout nets for the closed loop's observer / output step (one hidden unit per lane)
+    const bool loop_ok = hidden == HID && nu == 1 && ny == 1 && nx >= 2 && nx <= 4;
+    auto upload_plain = [&](const float* const* p, int n_in, int n_out, float** dst) -> int {
+        const int sz[8] = {n_out * n_in, n_out, hidden * n_in, hidden, hidden * hidden, hidden, n_out * hidden, n_out};
+        std::vector<float> e;
+        for (int i = 0; i < 8; ++i) e.insert(e.end(), p[i], p[i] + sz[i]);
+        for (int k = 0; k < hidden; ++k)            // W2 transposed, appended for lane-coalesced reads
+            for (int i = 0; i < hidden; ++i) e.push_back(p[4][i * hidden + k]);
+        NMPC_HIP_CHECK(hipMalloc(dst, e.size() * sizeof(float)));
+        NMPC_HIP_CHECK(hipMemcpy(*dst, e.data(), e.size() * sizeof(float), hipMemcpyHostToDevice));
+        return 0;
+    };
+    NMPC_REQUIRE(!enc || loop_ok, "nmpc_model_create: an observer net needs hidden = 64, nu = ny = 1, nx = 2..4");
+    if (loop_ok) {
+        if (upload_plain(hn, nx, ny, &m->d.hplain)) return 1;
+        if (enc && upload_plain(enc, n_enc_in, nx, &m->d.enc)) return 1;
+    }
+    if (!narrow) {           // no 64-wide packs: the general-width kernel serves the embedding
         *out = m;
         return 0;
     }
@@ -254,18 +270,6 @@ extern "C" int nmpc_model_create(nmpc_model** out, int nx, int nu, int ny, int h
         NMPC_HIP_CHECK(hipMalloc(&m->d.hpack_h2, PACK_FLOATS * sizeof(float)));
         NMPC_HIP_CHECK(hipMemcpy(m->d.hpack_h2, buf2.data(), PACK_FLOATS * sizeof(float), hipMemcpyHostToDevice));
     }
-    auto upload_plain = [&](const float* const* p, int n_in, int n_out, float** dst) -> int {
-        const int sz[8] = {n_out * n_in, n_out, hidden * n_in, hidden, hidden * hidden, hidden, n_out * hidden, n_out};
-        std::vector<float> e;
-        for (int i = 0; i < 8; ++i) e.insert(e.end(), p[i], p[i] + sz[i]);
-        for (int k = 0; k < hidden; ++k)            // W2 transposed, appended for lane-coalesced reads
-            for (int i = 0; i < hidden; ++i) e.push_back(p[4][i * hidden + k]);
-        NMPC_HIP_CHECK(hipMalloc(dst, e.size() * sizeof(float)));
-        NMPC_HIP_CHECK(hipMemcpy(*dst, e.data(), e.size() * sizeof(float), hipMemcpyHostToDevice));
-        return 0;
-    };
-    if (upload_plain(hn, nx, ny, &m->d.hplain)) return 1;
-    if (enc && upload_plain(enc, n_enc_in, nx, &m->d.enc)) return 1;
     *out = m;
     return 0;
 }

@@ -21,10 +21,10 @@ namespace nmpc {
 struct TargetArgs {
     int nb, nsamp, max_lpv;
     double tol, umin, umax, ymin, ymax, h0;
-    double f0[4];
+    double f0[8];
     // state-constrained variant (mpcUtil.py:167-239 getXsUs): fixed output row Cfix, box on xs itself
     int state;
-    double Cfix[4], xmin[4], xmax[4];
+    double Cfix[8], xmin[8], xmax[8];
     const double* yref;
     double *Xs, *Us, *Es;
     int *iters, *status;
@@ -154,9 +154,13 @@ static int target_run(const nmpc_model* m, TargetArgs a, const float* lam, const
             if (i > 0) { ea.count_dev = a.counts + i; ea.act = a.act + (size_t)(i & 1) * nb; }
             rc = embed_launch(m->d, ea, nt, s);
             if (rc) break;
-            if (nx == 2) hipLaunchKernelGGL((target_kernel<2>), dim3(grid), dim3(threads), 0, s, a, j, i);
-            else if (nx == 3) hipLaunchKernelGGL((target_kernel<3>), dim3(grid), dim3(threads), 0, s, a, j, i);
-            else { set_error("nmpc_target_select: nx=%d unsupported", nx); rc = 1; }
+            switch (nx) {
+#define NMPC_TARGET_CASE(NX_) case NX_: hipLaunchKernelGGL((target_kernel<NX_>), dim3(grid), dim3(threads), 0, s, a, j, i); break;
+                NMPC_TARGET_CASE(1) NMPC_TARGET_CASE(2) NMPC_TARGET_CASE(3) NMPC_TARGET_CASE(4)
+                NMPC_TARGET_CASE(5) NMPC_TARGET_CASE(6) NMPC_TARGET_CASE(7) NMPC_TARGET_CASE(8)
+#undef NMPC_TARGET_CASE
+                default: set_error("nmpc_target_select: nx=%d unsupported (1..8)", nx); rc = 1;
+            }
         }
     }
     hipError_t e1 = hipStreamSynchronize(s);

@@ -52,7 +52,7 @@ def mpc_qp(list_A, list_B, list_C, x0, y_meas, Xs, Us, f0, h0, Q, R, rho, u_min,
     lA = _f64(list_A); dev = lA.device
     batch = lA.shape[:-2]
     nb = int(np.prod(batch)) if len(batch) else 1
-    if nx > 3:                                   # the fused kernel is built for nx = 2 and 3
+    if nx > 4:                                   # the fused kernel is built for nx = 2..4
         return _mpc_qp_composed(lA, list_B, list_C, x0, y_meas, Xs, Us, f0, h0, Q, R, rho, u_min, u_max, y_min, y_max,
                                 Nc, nx, want_matrices)
     lB = _f64(list_B, dev).reshape(batch + (Nc * nx,)); lC = _f64(list_C, dev).reshape(batch + (Nc, nx))
@@ -79,7 +79,7 @@ def mpc_qp(list_A, list_B, list_C, x0, y_meas, Xs, Us, f0, h0, Q, R, rho, u_min,
 
 def _mpc_qp_composed(lA, list_B, list_C, x0, y_meas, Xs, Us, f0, h0, Q, R, rho, u_min, u_max, y_min, y_max, Nc, nx,
                      want_matrices):
-    """The same QP for state dimensions beyond the fused kernel (nx > 3): condensing kernel
+    """The same QP for state dimensions beyond the fused kernel (nx > 4): condensing kernel
     (nmpc_condense), batched dense products for G, F, L, h, batched QP kernel (nmpc_qp_solve)."""
     from .mpcutil import getPhi, getGamma, getF0
     from .qp import solve_qp
@@ -130,8 +130,8 @@ class Controller:
                  nodes, weights, tol=1e-1, rho=1000.0, state_feedback=None):
         """state_feedback: None for the output-feedback controller, or a dict(x_min, x_max [nx] normalised
         state bounds, y0, ystd [nx] state normalisation, hard=bool) for the state-feedback controllers."""
-        if encoder.nx not in (2, 3):
-            raise _lib.NmpcError("closed-loop controllers support nx = 2 or 3 (model has nx = %d)" % encoder.nx)
+        if encoder.nx not in (2, 3, 4):
+            raise _lib.NmpcError("closed-loop controllers support nx = 2..4 (model has nx = %d)" % encoder.nx)
         cfg = _lib.CtrlConfig()
         cfg.batch, cfg.Nc, cfg.max_iterations, cfg.n_sim = int(batch), int(Nc), int(max_iterations), int(Nsim)
         cfg.tol, cfg.rho = float(tol), float(rho)

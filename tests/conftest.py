@@ -65,29 +65,33 @@ def state_disc_model(seed=0, nl_scale=0.05):
     return Model(fn, hn, None, u0=u0, ustd=ustd, y0=0.0, ystd=1.0), y0, ystd
 
 
-def padded_disc_model(omodel, seed=5):
-    """The trained disc model embedded in a three-state model (nx = 3, nu = ny = 1, H = 64): the first
-    two states keep the trained nets, the third is a stable extra state coupled to them through small
+def padded_disc_model(omodel, seed=5, extra=1):
+    """The trained disc model embedded in a larger model (nx = 2 + extra, nu = ny = 1, H = 64): the first
+    two states keep the trained nets, the extra ones are stable states coupled to them through small
     random weights in every net (f, h and the observer), so the closed loop behaves like the
-    two-state one while every nx = 3 code path carries non-trivial numbers."""
+    two-state one while every code path of the larger state dimension carries non-trivial numbers."""
     import numpy as np
     from oracle.model import Model, ResNet
     rng = np.random.default_rng(seed)
     f32 = lambda a: np.asarray(a, np.float32)
     sm = lambda *shape: f32(0.05 * rng.standard_normal(shape))
     fn, hn, en = omodel.fn, omodel.hn, omodel.enc
-    # f: inputs (x1, x2, x3, u), outputs 3
-    lin_w = np.zeros((3, 4)); lin_w[:2, :2] = fn.lin_w[:, :2]; lin_w[:2, 3] = fn.lin_w[:, 2]
-    lin_w[:2, 2] = sm(2); lin_w[2] = [0.03, -0.02, 0.5, 0.04]
-    w0 = np.concatenate([fn.w0[:, :2], sm(64, 1), fn.w0[:, 2:3]], 1)
-    w4 = np.concatenate([fn.w4, sm(1, 64) / 8], 0)
-    f3 = ResNet(f32(lin_w), f32(np.append(fn.lin_b, 0.01)), f32(w0), f32(fn.b0), f32(fn.w2), f32(fn.b2), f32(w4),
-                f32(np.append(fn.b4, 0.0)))
-    # h: inputs (x1, x2, x3), output 1
-    h3 = ResNet(f32(np.concatenate([hn.lin_w, [[0.05]]], 1)), f32(hn.lin_b), f32(np.concatenate([hn.w0, sm(64, 1)], 1)),
+    e, nx = extra, 2 + extra
+    # f: inputs (x1, x2, extra states, u), outputs nx
+    lin_w = np.zeros((nx, nx + 1)); lin_w[:2, :2] = fn.lin_w[:, :2]; lin_w[:2, nx] = fn.lin_w[:, 2]
+    lin_w[:2, 2:nx] = sm(2, e)
+    lin_w[2:, :2] = 0.6 * sm(e, 2); lin_w[2:, nx] = 0.8 * sm(e)
+    lin_w[2:, 2:nx] = np.diag(0.5 - 0.15 * np.arange(e)) + 0.5 * sm(e, e)
+    w0 = np.concatenate([fn.w0[:, :2], sm(64, e), fn.w0[:, 2:3]], 1)
+    w4 = np.concatenate([fn.w4, sm(e, 64) / 8], 0)
+    f3 = ResNet(f32(lin_w), f32(np.concatenate([fn.lin_b, 0.01 * np.ones(e)])), f32(w0), f32(fn.b0), f32(fn.w2), f32(fn.b2),
+                f32(w4), f32(np.concatenate([fn.b4, np.zeros(e)])))
+    # h: inputs (x1, x2, extra states), output 1
+    h3 = ResNet(f32(np.concatenate([hn.lin_w, sm(1, e)], 1)), f32(hn.lin_b), f32(np.concatenate([hn.w0, sm(64, e)], 1)),
                 f32(hn.b0), f32(hn.w2), f32(hn.b2), f32(hn.w4), f32(hn.b4))
-    # observer: histories -> 3 states
+    # observer: histories -> nx states
     nh = en.w0.shape[1]
-    e3 = ResNet(f32(np.concatenate([en.lin_w, 0.4 * sm(1, nh)], 0)), f32(np.append(en.lin_b, 0.0)), f32(en.w0), f32(en.b0),
-                f32(en.w2), f32(en.b2), f32(np.concatenate([en.w4, 0.4 * sm(1, 64)], 0)), f32(np.append(en.b4, 0.0)))
+    e3 = ResNet(f32(np.concatenate([en.lin_w, 0.4 * sm(e, nh)], 0)), f32(np.concatenate([en.lin_b, np.zeros(e)])), f32(en.w0),
+                f32(en.b0), f32(en.w2), f32(en.b2), f32(np.concatenate([en.w4, 0.4 * sm(e, 64)], 0)),
+                f32(np.concatenate([en.b4, np.zeros(e)])))
     return Model(f3, h3, e3, u0=omodel.u0, ustd=omodel.ustd, y0=omodel.y0, ystd=omodel.ystd, na=omodel.na, nb=omodel.nb)
