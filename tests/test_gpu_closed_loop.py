@@ -220,6 +220,12 @@ def test_recorded_closed_loop_of_the_reference(enc):
     idx = recorded_run_windows(r[1], 450)
     assert np.abs(y[idx] - q[idx]).max() < 5e-3 and np.abs(u[idx] - w[idx]).max() < 2e-2
     assert np.median(np.abs(y - q)) < 6e-3
+    # Experiments/lpv_counter.npy: LPV passes per step of the run NMPC_test.py:324-368 describes (this
+    # configuration); the pass count follows from the step's QP solutions through the stop test
+    rec = np.load(os.path.join(GOLDEN, "ref_lpv_counter.npy"))
+    c = out[6].cpu().numpy().reshape(-1)
+    assert (c == rec).mean() >= 0.98 and abs(int(c.sum()) - int(rec.sum())) <= 3
+    assert np.array_equal(c[:60], rec[:60])
 
 
 def test_noisy_converged_configuration_at_scale(enc, omodel):

@@ -237,3 +237,24 @@ def test_recorded_closed_loop_of_the_reference(omodel):
     assert np.median(np.abs(y - q)) < 6e-3 and np.median(np.abs(o["u_log"] - w)) < 3e-2
     idx = recorded_run_windows(r[1], 450)
     assert len(idx) >= 50 and np.abs(y[idx] - q[idx]).max() < 5e-3 and np.abs(o["u_log"][idx] - w[idx]).max() < 2e-2
+
+
+def test_recorded_pass_counters_of_the_reference(omodel):
+    """Experiments/lpv_counter.npy of the reference: the number of LPV passes its controller took in
+    each of the 450 steps of the run its main block describes (NMPC_test.py:324-368: Nc = 10, stages
+    = 20, max_iterations = 4, Q = diag(1000, 10), R = 1, u in [-4, 4], y in [-1.2, 1.2], noise-free plant,
+    row 1 of references/randomLevelTime25_30Range-1_1Nsim500.npy, the SNR-30 encoder).  A pass count is
+    decided by the QP solutions of that step through the stop test ||u - u_old|| < tol
+    (NMPC_test.py:240-260), so the record pins the LPV iteration of the closed loop against the
+    reference's own solver: the oracle reproduces it in 446 of 450 steps and in the total."""
+    import os
+    from conftest import GOLDEN
+    from oracle.nmpc import output_nmpc_linear
+    rec = np.load(os.path.join(GOLDEN, "ref_lpv_counter.npy"))
+    r = np.load(os.path.join(GOLDEN, "ref_randomLevelTime25_30Range-1_1Nsim500.npy"))
+    o = output_nmpc_linear(omodel, -4, 4, [-1.2], [1.2], np.zeros(2), np.diag([1000.0, 10.0]), 1.0, 0.1, 20,
+                           np.clip(r[1], -1.2, 1.2), Nc=10, Nsim=450, max_iterations=4)
+    c = np.asarray(o["lpv_counter"])
+    assert c.shape == rec.shape == (450,)
+    assert (c == rec).mean() >= 0.98 and abs(int(c.sum()) - int(rec.sum())) <= 3
+    assert np.array_equal(c[:60], rec[:60])                    # start-up transient and first level change
