@@ -287,3 +287,21 @@ def test_closed_loop_larger_state_models(omodel, nx):
     check_parity(orc, out, ctrl, Nsim, nx=nx, target_tol=5e-5)
     y = out[8].cpu().numpy()
     assert np.median(np.abs(y[:, 1:] - refs[:, :Nsim])) < 0.1        # the loop still tracks
+
+
+def test_recorded_long_runs_of_the_reference(enc):
+    """Experiments/lpv_counter_tight.npy and lpv_counter_noise.npy of the reference: LPV passes per step of
+    two 4950-step runs on references/randomLevelTime25_30Range-1_1Nsim5000.npy whose exact settings are
+    not recorded (the names suggest tighter solver settings and a noisy plant).  Loose pin: the device
+    loop in the canonical noise-free configuration (NMPC_test.py:324-368) takes the same number of
+    passes in more than 96 % of the steps of either record and within 3 % of their totals."""
+    import nmpc_amd
+    r = np.load(os.path.join(GOLDEN, "ref_randomLevelTime25_30Range-1_1Nsim5000.npy"))
+    plant = nmpc_amd.OutputUnbalancedDisc(dt=0.1, sigma_n=[0.0])
+    out = nmpc_amd.output_NMPC_linear(plant, enc, -4, 4, [-1.2], [1.2], np.zeros(2), Q, 1.0, 0.1, 0.05, 20,
+                                      np.clip(r[1], -1.2, 1.2), Nc=10, Nsim=4950, max_iterations=4)
+    c = out[6].cpu().numpy().reshape(-1)
+    for name in ("tight", "noise"):
+        rec = np.load(os.path.join(GOLDEN, "ref_lpv_counter_%s.npy" % name))
+        assert rec.shape == c.shape == (4950,)
+        assert (c == rec).mean() > 0.96 and abs(int(c.sum()) - int(rec.sum())) < 0.03 * rec.sum()
