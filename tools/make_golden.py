@@ -19,6 +19,12 @@ Produces
                                  stand-ins of the horizon-mapped Get_A/Get_B/Get_C (lambda_simpson of the
                                  reference on the jacrev callables, Nc results side by side)
 (`--only ablist` writes just the last file.)
+
+`--only records` copies the data files of the reference that the tests use as they are (reference
+signals and the logs of its own recorded runs), under a `ref_` prefix:
+  references/randomLevelTime10_15Range-1_1Nsim200.npy, randomLevelTime25_30Range-1_1Nsim500.npy,
+  randomLevelTime25_30Range-1_1Nsim5000.npy; Experiments/log_q.npy, log_w.npy, lpv_counter.npy,
+  lpv_counter_tight.npy, lpv_counter_noise.npy, components_time.npy
 """
 import os
 import sys
@@ -91,7 +97,25 @@ def make_ablist(mpcUtil, lpv_int):
     np.savez_compressed(os.path.join(OUT, "ref_ablist.npz"), **out)
 
 
+RECORDS = ["references/randomLevelTime10_15Range-1_1Nsim200.npy", "references/randomLevelTime25_30Range-1_1Nsim500.npy",
+           "references/randomLevelTime25_30Range-1_1Nsim5000.npy", "Experiments/log_q.npy", "Experiments/log_w.npy",
+           "Experiments/lpv_counter.npy", "Experiments/lpv_counter_tight.npy", "Experiments/lpv_counter_noise.npy",
+           "Experiments/components_time.npy"]
+
+
+def copy_records():
+    """Data files of the reference, loaded as plain arrays (no pickle) and re-saved under tests/golden/."""
+    os.makedirs(OUT, exist_ok=True)
+    for rel in RECORDS:
+        a = np.load(os.path.join(REF, rel), allow_pickle=False)
+        np.save(os.path.join(OUT, "ref_" + os.path.basename(rel)), a)
+        print("copied", rel, a.shape, a.dtype)
+
+
 def main():
+    if sys.argv[1:3] == ["--only", "records"]:
+        copy_records()
+        return
     import torch
     from torch.func import jacrev, vmap
     mpcUtil, lpv_int, lpv_rk4 = load_reference()
