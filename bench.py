@@ -121,7 +121,7 @@ def main():
                     help="diagnostic: record no HIP event pairs (roofline fields become null)")
     ap.add_argument("--event-every", type=int, default=EVENT_EVERY,
                     help="bracket the kernel launches of every n-th step with HIP event pairs")
-    ap.add_argument("--cpu-controllers", type=int, default=10)
+    ap.add_argument("--cpu-controllers", type=int, default=12)
     ap.add_argument("--cpu-steps", type=int, default=200)
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="diagnostic: run the N-rank path with every rank on cuda:0 and the gloo backend")
