@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <cstdarg>
 #include <cstdio>
 #include <string>
@@ -9,6 +11,16 @@
 namespace nmpc {
 
 void set_error(const char* fmt, ...);
+
+// hipFuncSetAttribute acts on the current device only: `mask` (one per kernel) remembers the devices
+// on which the attribute has been set.  True the first time it is called on a device.
+inline bool first_use_on_device(std::atomic<unsigned long long>& mask) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (mask.load(std::memory_order_relaxed) & bit) return false;
+    return (mask.fetch_or(bit) & bit) == 0;
+}
 
 #define NMPC_HIP_CHECK(expr)                                                                  \
     do {                                                                                      \

@@ -481,7 +481,9 @@ extern "C" int nmpc_ctrl_run(nmpc_ctrl* c, int k0, int nsteps, const double* Xs,
         sl_rp.push_back(rp);
         (void)d; (void)s;
     }
-    // steps are issued slice by slice within a step so that the streams stay evenly fed
+    // steps are issued slice by slice within a step so that the streams stay evenly fed; a failed launch
+    // stops the issue, and the slice streams are joined to the caller's stream in either case
+    auto issue = [&]() -> int {
     for (int k = k0; k < k0 + nsteps; ++k) {
         c->prof_on = c->prof_every > 0 && k % c->prof_every == 0;
         for (size_t i = 0; i < c->slices.size(); ++i) {
@@ -515,12 +517,15 @@ extern "C" int nmpc_ctrl_run(nmpc_ctrl* c, int k0, int nsteps, const double* Xs,
             prof_end(c, on, s, pr);
         }
     }
+    return 0;
+    };
+    const int rc = issue();
     if (multi)
         for (CtrlSlice& sl : c->slices) {
             NMPC_HIP_CHECK(hipEventRecord(sl.done, sl.stream));
             NMPC_HIP_CHECK(hipStreamWaitEvent(s0, sl.done, 0));
         }
-    return 0;
+    return rc;
 }
 
 extern "C" int nmpc_ctrl_profile(nmpc_ctrl* c, int enable) {

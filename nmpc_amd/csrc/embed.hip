@@ -437,12 +437,10 @@ __global__ __launch_bounds__(EMBED_THREADS, 3) void embed_kernel(EmbedArgs a, No
 
 template <int NX, int NU, int NY, bool LOOP, bool H2>
 static int embed_launch_t(const EmbedArgs& a, const NodeTable& nt, int grid, size_t lds_bytes, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_set{0};
+    if (first_use_on_device(attr_set))
         NMPC_HIP_CHECK(hipFuncSetAttribute((const void*)embed_kernel<NX, NU, NY, LOOP, H2>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
     hipLaunchKernelGGL((embed_kernel<NX, NU, NY, LOOP, H2>), dim3(grid), dim3(EMBED_THREADS), lds_bytes, stream, a, nt);
     NMPC_HIP_CHECK(hipGetLastError());
     return 0;

@@ -186,13 +186,12 @@ __global__ __launch_bounds__(256, 1) void embed_wide_kernel(WideArgs a, NodeTabl
 template <int HT, int NOUT>
 static int wide_launch_t(const WideArgs& a, const NodeTable& nt, int grid, hipStream_t s, bool loop) {
     constexpr size_t lds = sizeof(float) * wide_lds_floats<HT, NOUT>();
-    static bool once = false;
-    if (!once) {
+    static std::atomic<unsigned long long> once{0};
+    if (first_use_on_device(once)) {
         NMPC_HIP_CHECK(hipFuncSetAttribute((const void*)embed_wide_kernel<HT, NOUT, false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         NMPC_HIP_CHECK(hipFuncSetAttribute((const void*)embed_wide_kernel<HT, NOUT, true>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        once = true;
     }
     if (loop) hipLaunchKernelGGL((embed_wide_kernel<HT, NOUT, true>), dim3(grid), dim3(256), lds, s, a, nt);
     else hipLaunchKernelGGL((embed_wide_kernel<HT, NOUT, false>), dim3(grid), dim3(256), lds, s, a, nt);

@@ -199,20 +199,12 @@ using namespace nmpc;
 extern "C" const char* nmpc_last_error(void) { return g_err.c_str(); }
 extern "C" int nmpc_version(void) { return 100; }
 
-extern "C" int nmpc_model_create(nmpc_model** out, int nx, int nu, int ny, int hidden, int n_enc_in,
-                                 const float* const* fn, const float* const* hn,
-                                 const float* const* enc) {
-    NMPC_REQUIRE(out && fn && hn, "nmpc_model_create: null argument");
-    NMPC_REQUIRE(hidden >= 1 && hidden <= 256, "nmpc_model_create: hidden width %d unsupported (1..256)", hidden);
-    NMPC_REQUIRE(nx >= 1 && nu >= 1 && ny >= 1 && nx <= 8 && nx + nu <= 16 && ny <= 8,
-                 "nmpc_model_create: dims nx=%d nu=%d ny=%d unsupported (need nx<=8, nx+nu<=16, ny<=8)", nx, nu, ny);
+// Packs and uploads the nets into `m` (zero-initialised); on failure the caller destroys `m`.
+static int model_fill(nmpc_model* m, int nx, int nu, int ny, int hidden, int n_enc_in, const float* const* fn,
+                      const float* const* hn, const float* const* enc) {
     // the 64-wide kernels (embed.hip) are instantiated for these sizes; everything else runs on the
     // general-width kernel (embed_wide.hip)
     const bool narrow = hidden == HID && nu == 1 && ny == 1 && (nx == 2 || nx == 3);
-    NMPC_REQUIRE(!enc || (n_enc_in >= 1 && n_enc_in <= 32), "nmpc_model_create: bad encoder input size %d",
-                 n_enc_in);
-    nmpc_model* m = new nmpc_model();
-    std::memset(m, 0, sizeof(*m));
     m->d.nx = nx; m->d.nu = nu; m->d.ny = ny; m->d.hidden = hidden; m->d.n_enc_in = enc ? n_enc_in : 0;
     NMPC_HIP_CHECK(hipGetDevice(&m->device));
     m->d.narrow_ok = narrow ? 1 : 0;
@@ -252,7 +244,6 @@ extern "C" int nmpc_model_create(nmpc_model** out, int nx, int nu, int ny, int h
         if (enc && upload_plain(enc, n_enc_in, nx, &m->d.enc)) return 1;
     }
     if (!narrow) {           // no 64-wide packs: the general-width kernel serves the embedding
-        *out = m;
         return 0;
     }
     std::vector<float> buf;
@@ -269,6 +260,24 @@ extern "C" int nmpc_model_create(nmpc_model** out, int nx, int nu, int ny, int h
         NMPC_HIP_CHECK(hipMemcpy(m->d.fpack_h2, buf.data(), PACK_FLOATS * sizeof(float), hipMemcpyHostToDevice));
         NMPC_HIP_CHECK(hipMalloc(&m->d.hpack_h2, PACK_FLOATS * sizeof(float)));
         NMPC_HIP_CHECK(hipMemcpy(m->d.hpack_h2, buf2.data(), PACK_FLOATS * sizeof(float), hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+extern "C" int nmpc_model_create(nmpc_model** out, int nx, int nu, int ny, int hidden, int n_enc_in,
+                                 const float* const* fn, const float* const* hn,
+                                 const float* const* enc) {
+    NMPC_REQUIRE(out && fn && hn, "nmpc_model_create: null argument");
+    NMPC_REQUIRE(hidden >= 1 && hidden <= 256, "nmpc_model_create: hidden width %d unsupported (1..256)", hidden);
+    NMPC_REQUIRE(nx >= 1 && nu >= 1 && ny >= 1 && nx <= 8 && nx + nu <= 16 && ny <= 8,
+                 "nmpc_model_create: dims nx=%d nu=%d ny=%d unsupported (need nx<=8, nx+nu<=16, ny<=8)", nx, nu, ny);
+    NMPC_REQUIRE(!enc || (n_enc_in >= 1 && n_enc_in <= 32), "nmpc_model_create: bad encoder input size %d",
+                 n_enc_in);
+    nmpc_model* m = new nmpc_model();
+    std::memset(m, 0, sizeof(*m));
+    if (model_fill(m, nx, nu, ny, hidden, n_enc_in, fn, hn, enc)) {
+        nmpc_model_destroy(m);          // frees whatever was uploaded before the failure
+        return 1;
     }
     *out = m;
     return 0;

@@ -431,8 +431,8 @@ static int set_lds_attr(K kernel) {
 // NC: horizon as a compile-time constant (0 = read it from the arguments)
 template <int GS, int MPL, int NX, int NC = 0>
 static int launch_mpc_qp(const MpcQpArgs& a, const MpcGeom& g, hipStream_t s) {
-    static bool once = false;
-    if (!once) { if (set_lds_attr(mpc_qp_kernel<GS, MPL, NX, NC>)) return 1; once = true; }
+    static std::atomic<unsigned long long> once{0};
+    if (first_use_on_device(once) && set_lds_attr(mpc_qp_kernel<GS, MPL, NX, NC>)) return 1;
     hipLaunchKernelGGL((mpc_qp_kernel<GS, MPL, NX, NC>), dim3((a.nb + g.gpb - 1) / g.gpb), dim3(g.gpb * GS), g.lds, s, a);
     NMPC_HIP_CHECK(hipGetLastError());
     return 0;
@@ -440,8 +440,8 @@ static int launch_mpc_qp(const MpcQpArgs& a, const MpcGeom& g, hipStream_t s) {
 
 template <int GS, int MPL, int NX, int NC = 0>
 static int launch_mpc_solve(const CtrlDev& d, const RunPtrs& rp, int it, int k, const MpcGeom& g, hipStream_t s) {
-    static bool once = false;
-    if (!once) { if (set_lds_attr(mpc_solve_kernel<GS, MPL, NX, NC>)) return 1; once = true; }
+    static std::atomic<unsigned long long> once{0};
+    if (first_use_on_device(once) && set_lds_attr(mpc_solve_kernel<GS, MPL, NX, NC>)) return 1;
     hipLaunchKernelGGL((mpc_solve_kernel<GS, MPL, NX, NC>), dim3((d.B + g.gpb - 1) / g.gpb), dim3(g.gpb * GS), g.lds, s, d, rp, it, k);
     NMPC_HIP_CHECK(hipGetLastError());
     return 0;
