@@ -13,7 +13,10 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is
  *     asynchronous on it; no entry point synchronises the device unless stated;
  *   - return value 0 = ok, non-zero = error, message via nmpc_last_error() (thread-local);
- *   - nothing here allocates device memory per call except the *_create functions.
+ *   - nothing here allocates device memory per call except the *_create functions and the pre-loop
+ *     target selectors (which say so);
+ *   - a model or controller handle is used with the device that was current at its creation
+ *     current again (one process per GPU needs no care; other callers get an error otherwise).
  */
 #ifndef NMPC_AMD_H
 #define NMPC_AMD_H

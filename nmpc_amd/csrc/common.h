@@ -22,6 +22,12 @@ inline bool first_use_on_device(std::atomic<unsigned long long>& mask) {
     return (mask.fetch_or(bit) & bit) == 0;
 }
 
+// a handle's device memory belongs to the device that was current when it was created
+inline bool on_device(int device) {
+    int dev = -1;
+    return hipGetDevice(&dev) == hipSuccess && dev == device;
+}
+
 #define NMPC_HIP_CHECK(expr)                                                                  \
     do {                                                                                      \
         hipError_t _e = (expr);                                                               \

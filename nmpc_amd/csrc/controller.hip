@@ -340,6 +340,7 @@ static void prof_end(nmpc_ctrl* c, bool on, hipStream_t s, ProfRec& r) {
 
 extern "C" int nmpc_ctrl_create(nmpc_ctrl** out, const nmpc_model* m, const nmpc_ctrl_config* cfg) {
     NMPC_REQUIRE(out && m && cfg, "nmpc_ctrl_create: null argument");
+    NMPC_REQUIRE(on_device(m->device), "nmpc_ctrl_create: the model lives on device %d, which is not the current device", m->device);
     NMPC_REQUIRE(m->d.nu == 1 && m->d.ny == 1, "nmpc_ctrl_create: closed loop needs nu = ny = 1 (as the reference)");
     const int mode = cfg->mode;
     NMPC_REQUIRE(mode == 0 || mode == 1, "nmpc_ctrl_create: mode %d unknown (0 output feedback, 1 state feedback)", mode);
@@ -443,6 +444,7 @@ extern "C" void nmpc_ctrl_destroy(nmpc_ctrl* c) {
 
 extern "C" int nmpc_ctrl_reset(nmpc_ctrl* c, const double* x0n, double u0n, const double* plant_x0, void* stream) {
     NMPC_REQUIRE(c && x0n, "nmpc_ctrl_reset: null argument");
+    NMPC_REQUIRE(on_device(c->device), "nmpc_ctrl_reset: the controllers live on device %d, which is not the current device", c->device);
     double x0[4] = {0, 0, 0, 0};
     for (int r = 0; r < c->d.nx; ++r) x0[r] = x0n[r];
     const double pw = plant_x0 ? plant_x0[0] : 0.0, pth = plant_x0 ? plant_x0[1] : 0.0;
@@ -459,6 +461,7 @@ extern "C" int nmpc_ctrl_run(nmpc_ctrl* c, int k0, int nsteps, const double* Xs,
                              double* x_log, double* u_log, double* e_log, double* y_log, double* y_est_log,
                              int* lpv_counter, double* plan_log, void* stream) {
     NMPC_REQUIRE(c && Xs && Us, "nmpc_ctrl_run: null argument");
+    NMPC_REQUIRE(on_device(c->device), "nmpc_ctrl_run: the controllers live on device %d, which is not the current device", c->device);
     NMPC_REQUIRE(k0 >= 0 && nsteps >= 0 && k0 + nsteps <= c->d.n_sim, "nmpc_ctrl_run: steps [%d,%d) outside n_sim=%d", k0,
                  k0 + nsteps, c->d.n_sim);
     std::vector<RunPtrs> sl_rp;

@@ -512,6 +512,7 @@ extern "C" int nmpc_lpv_embed(const nmpc_model* m, int npts, const float* x, con
                               const float* lam, const float* w, int n_nodes, float* A, float* B, float* C,
                               void* stream) {
     NMPC_REQUIRE(m && lam && w, "nmpc_lpv_embed: null argument");
+    NMPC_REQUIRE(on_device(m->device), "nmpc_lpv_embed: the model lives on device %d, which is not the current device", m->device);
     NMPC_REQUIRE(n_nodes >= 1 && n_nodes <= NMPC_MAX_NODES, "nmpc_lpv_embed: n_nodes=%d out of [1,%d]", n_nodes,
                  NMPC_MAX_NODES);
     NMPC_REQUIRE(npts >= 0, "nmpc_lpv_embed: negative point count");

@@ -176,6 +176,7 @@ extern "C" int nmpc_target_select(const nmpc_model* m, int nb, int nsamp, const 
                                   int n_nodes, int max_lpv, double tol, double* Xs, double* Us, double* Es,
                                   int* iters, int* status, void* stream) {
     NMPC_REQUIRE(m && y_ref_n && lam && w && Xs && Us && Es && status, "nmpc_target_select: null argument");
+    NMPC_REQUIRE(on_device(m->device), "nmpc_target_select: the model lives on device %d, which is not the current device", m->device);
     NMPC_REQUIRE(m->d.nu == 1 && m->d.ny == 1, "nmpc_target_select: needs nu = ny = 1 (as the reference)");
     NMPC_REQUIRE(nb >= 1 && nsamp >= 1 && max_lpv >= 1 && max_lpv <= 1024, "nmpc_target_select: bad sizes");
     NMPC_REQUIRE(n_nodes >= 1 && n_nodes <= NMPC_MAX_NODES, "nmpc_target_select: bad node count");
@@ -194,6 +195,7 @@ extern "C" int nmpc_target_select_state(const nmpc_model* m, int nb, int nsamp, 
                                         int* status, void* stream) {
     NMPC_REQUIRE(m && y_ref_n && x_min && x_max && C && lam && w && Xs && Us && Es && status,
                  "nmpc_target_select_state: null argument");
+    NMPC_REQUIRE(on_device(m->device), "nmpc_target_select_state: the model lives on device %d, which is not the current device", m->device);
     NMPC_REQUIRE(m->d.nu == 1, "nmpc_target_select_state: needs nu = 1 and one output row (as the reference)");
     NMPC_REQUIRE(nb >= 1 && nsamp >= 1 && max_lpv >= 1 && max_lpv <= 1024, "nmpc_target_select_state: bad sizes");
     NMPC_REQUIRE(n_nodes >= 1 && n_nodes <= NMPC_MAX_NODES, "nmpc_target_select_state: bad node count");
