@@ -50,7 +50,7 @@ constexpr int HID = 64;             // hidden width handled by the MFMA embeddin
 // Packed-net layout (float offsets), see pack_net in model.cpp.
 constexpr int PK_WF = 0;          // [4][4][64][4]    forward A-fragments of c2*W2
 constexpr int PK_WR = 4096;       // [4][4][4][64][4] reverse A-fragments of (4 W4[c]) .* W2^T, c = 0..3
-constexpr int PK_REC1 = 20480;    // [64][4] {c2*b0[k], c2*b2[k], 0, 0}
+constexpr int PK_REC1 = 20480;    // [64][4] {c2*b0[k], c2*b2[k], split-fp16 pack: inverse scale of reverse matrix k (k < 4), 0}
 constexpr int PK_REC2 = 20736;    // [64][4] W0[k][0..3] (zero padded)
 constexpr int PK_LIN = 20992;     // [4][4]  W_lin[c][j] (zero padded)
 constexpr int PK_J0 = 21008;      // [4][4]  Jacobian of the nonlinear branch at the origin, W4 D2 W2 D1 W0 (fp64-evaluated)

@@ -390,7 +390,7 @@ __device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, fl
     for (int c = 0; c < NOUT; ++c)
 #pragma unroll
         for (int j = 0; j < NIN; ++j) {
-            float v = wlast * pj[c][j];
+            float v = (wlast * lds[L_REC1 + 4 * c + 2]) * pj[c][j];     // weight of the last run, inverse pack scale of row c
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
             if (hq == 0) red[(wave * EMBED_TILE + n) * (NOUT * NIN) + c * NIN + j] = v;

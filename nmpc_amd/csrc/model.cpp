@@ -71,7 +71,7 @@ static void pack_net(const float* const* p, int n_in, int n_out, std::vector<flo
 
 // Split-fp16 packing: every fragment element W is stored as two halves, Wh = fp16(W) and
 // Wl = fp16(W - Wh) (unscaled; subnormal for |W| < 1/8, absolute resolution 2^-24).  Returns false
-// when the fragments do not suit that format: an entry beyond the fp16 range, or a matrix whose
+// when the fragments do not suit that format: an entry beyond the fp16 range, or a forward matrix whose
 // largest entry is below 2^-6 (the absolute resolution would cost relative accuracy).  Fragment of tile T, k-step ks: lane l (row 16T + (l&15), quarter
 // hq = l>>4) holds 8 halves j = 0..7 for the hidden unit 16 (2 ks + (j>>2)) + 4 hq + (j&3), i.e.
 // unit s = 8 ks + j in the kernel's numbering.  Region layout: [plane][T][ks][lane][8 halves].
@@ -94,6 +94,21 @@ static bool pack_net_h2(const float* const* p, int n_in, int n_out, std::vector<
         reg[((((size_t)0 * 4 + T) * 2 + ks) * 64 + lane) * 8 + j] = h;
         reg[((((size_t)1 * 4 + T) * 2 + ks) * 64 + lane) * 8 + j] = l;
     };
+    // Each reverse matrix is stored times a power of two that brings its largest entry into [0.5, 1), so
+    // that the unscaled fp16 remainders resolve it to 2^-24 of that entry whatever the size of W4's
+    // row; the kernel multiplies the accumulated row by the inverse (REC1[4 c + 2]) once at the end.
+    double rscale[4] = {1.0, 1.0, 1.0, 1.0};
+    for (int c = 0; c < n_out; ++c) {
+        double mx = 0.0;
+        for (int k = 0; k < HID; ++k)
+            for (int i = 0; i < HID; ++i) mx = std::fmax(mx, std::fabs((double)w2[k * HID + i] * 4.0 * (double)w4[c * HID + k]));
+        if (mx > 0.0 && std::isfinite(mx)) {
+            int e = 0;
+            std::frexp(mx, &e);                       // mx = f 2^e, f in [0.5, 1)
+            rscale[c] = std::ldexp(1.0, -e);
+        }
+        out[PK_REC1 + 4 * c + 2] = (float)(1.0 / rscale[c]);
+    }
     for (int T = 0; T < 4; ++T)
         for (int ks = 0; ks < 2; ++ks)
             for (int lane = 0; lane < 64; ++lane)
@@ -102,7 +117,8 @@ static bool pack_net_h2(const float* const* p, int n_in, int n_out, std::vector<
                     const int k = 16 * (2 * ks + (j >> 2)) + 4 * hq + (j & 3);
                     put(PK_WF, T, ks, lane, j, 2.0 * c2 * (double)w2[(16 * T + r) * HID + k]);
                     for (int c = 0; c < n_out; ++c)
-                        put(PK_WR + 4096 * c, T, ks, lane, j, (double)w2[k * HID + 16 * T + r] * 4.0 * (double)w4[c * HID + k]);
+                        put(PK_WR + 4096 * c, T, ks, lane, j,
+                            rscale[c] * (double)w2[k * HID + 16 * T + r] * 4.0 * (double)w4[c * HID + k]);
                 }
     // The forward product takes r = (1 + t1) / 2 = 1 / (1 + 2^-a) as its operand instead of t1 = tanh:
     // W2 t1 + b2 = (2 W2) r + (b2 - W2 1); the fragments above carry the 2, the bias the constant.
@@ -112,8 +128,9 @@ static bool pack_net_h2(const float* const* p, int n_in, int n_out, std::vector<
         for (int i = 0; i < HID; ++i) a -= (double)w2[k * HID + i];
         out[PK_REC1 + 4 * k + 1] = (float)(c2 * a);
     }
-    for (int i = 0; i <= n_out; ++i)
-        if (wmax[i] < 1.0 / 64.0) ok = false;
+    if (wmax[0] < 1.0 / 64.0) ok = false;          // forward matrix (not rescaled: its product feeds exp2 directly)
+    for (int c = 0; c < n_out; ++c)
+        if (!(wmax[1 + c] > 0.0)) ok = false;      // an all-zero output row: leave it to the fp32 kernel
     return ok;
 }
 
