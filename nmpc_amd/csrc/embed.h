@@ -16,6 +16,11 @@ struct NodeTable {
     float w_sum;    // total weight of all nodes (multiplies the linear branch)
     float lam[NMPC_MAX_NODES];
     float w[NMPC_MAX_NODES];
+    // set by embed_launch: recur = 1 if the nodes of every wave's quarter [n*w/4, n*(w+1)/4) are equally
+    // spaced, dlam[w] = that spacing (the split-fp16 kernel then steps 2^-a from node to node by a
+    // multiplication instead of evaluating it)
+    int recur;
+    float dlam[4];
 };
 
 struct EmbedArgs {

@@ -21,6 +21,7 @@
 #include "common.h"
 #include "embed.h"
 
+#include <cmath>
 #include <cstdlib>
 #include <algorithm>
 #include <string>
@@ -236,9 +237,16 @@ __device__ __forceinline__ void split16(const float* v, f16x8* BH, f16x8* BL) {
         BH[ks] = __builtin_bit_cast(f16x8, h);
         BL[ks] = __builtin_bit_cast(f16x8, l);
     }
+    // The compiler's hazard recognizer does not see the VALU writes made inside inline asm, so the two
+    // wait states an MFMA needs after a VALU write of one of its operands are supplied here, once per
+    // split: every MFMA that takes BH / BL is ordered after this statement.  (Without it one
+    // instantiation read a stale half of a B operand: an MFMA one instruction behind the v_fma_mixhi.)
+    asm volatile("s_nop 1" : "+v"(BH[0]), "+v"(BH[1]), "+v"(BL[0]), "+v"(BL[1]));
 }
 
-template <int NA, int NB, int NOUT>
+// RECUR: the nodes of a wave are equally spaced (nt.dlam): e = 2^-a of layer 1 is stepped from node to
+// node by one multiplication with 2^(-dlam g) instead of being evaluated (a = lam g + b0 is linear in lam).
+template <int NA, int NB, int NOUT, bool RECUR = false>
 __device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, float* __restrict__ lds,
                                               const float* __restrict__ pa, const float* __restrict__ pb,
                                               float* __restrict__ oa, float* __restrict__ ob, int tile, int npts,
@@ -309,6 +317,16 @@ __device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, fl
     // The node weight is applied once per run of equal weights (the host orders the nodes by weight):
     // q holds the sum in units of the current weight and is rescaled when the weight changes.
     float wcur = n0 < n1 ? nt.w[n0] : 0.0f;
+    float e1[16], rho[16];
+    if constexpr (RECUR) {
+        const float lam0 = n0 < n1 ? nt.lam[n0] : 0.0f, dl = nt.dlam[wave];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            e1[s] = __builtin_amdgcn_exp2f(-fmaf(lam0, g[s], b0[s]));
+            // the step factor stays finite and non-zero, so inf / 0 (saturated units) propagate as they are
+            rho[s] = __builtin_amdgcn_exp2f(fminf(fmaxf(-dl * g[s], -64.0f), 64.0f));
+        }
+    }
     for (int node = n0; node < n1; ++node) {
         const float lam = nt.lam[node];
         const float wn = nt.w[node];
@@ -325,8 +343,10 @@ __device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, fl
         float r1[16], wd1[16];                     // r1 = (1 + t1) / 2 is the operand of the forward product
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const float a = fmaf(lam, g[s], b0[s]);
-            const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-a));
+            float e;
+            if constexpr (RECUR) { e = e1[s]; e1[s] = e * rho[s]; }
+            else e = __builtin_amdgcn_exp2f(-fmaf(lam, g[s], b0[s]));
+            const float r = __builtin_amdgcn_rcpf(1.0f + e);
             r1[s] = r;
             wd1[s] = fmaf(-r, r, r);               // (1 - t1^2) / 4
         }
@@ -416,8 +436,8 @@ __device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, fl
 
 // LOOP tags the launches made from the closed-loop step so that a profiler lists them apart from
 // the set-up launches (target selector, stand-alone calls); the code is identical.
-// H2 selects the split-fp16 matrix path (embed_tile_h2) instead of the fp32 MFMA path.
-template <int NX, int NU, int NY, bool LOOP, bool H2>
+// MODE: 0 fp32 MFMA path (embed_tile), 1 split-fp16 path (embed_tile_h2), 2 the same with the node recurrence.
+template <int NX, int NU, int NY, bool LOOP, int MODE>
 __global__ __launch_bounds__(EMBED_THREADS, 3) void embed_kernel(EmbedArgs a, NodeTable nt) {
     extern __shared__ __align__(16) float lds[];
     int npts = a.npts;
@@ -425,23 +445,23 @@ __global__ __launch_bounds__(EMBED_THREADS, 3) void embed_kernel(EmbedArgs a, No
     const int b = blockIdx.x;
     if (b < a.n_ftiles) {
         if (b * EMBED_TILE >= npts) return;
-        if (H2) embed_tile_h2<NX, NU, NX>(a.fpack, lds, a.x, a.u, a.A, a.B, b, npts, a.act, a.group, nt);
-        else embed_tile<NX, NU, NX>(a.fpack, lds, a.x, a.u, a.A, a.B, b, npts, a.act, a.group, nt);
+        if constexpr (MODE == 0) embed_tile<NX, NU, NX>(a.fpack, lds, a.x, a.u, a.A, a.B, b, npts, a.act, a.group, nt);
+        else embed_tile_h2<NX, NU, NX, MODE == 2>(a.fpack, lds, a.x, a.u, a.A, a.B, b, npts, a.act, a.group, nt);
     } else {
         const int t = b - a.n_ftiles;
         if (t * EMBED_TILE >= npts) return;
-        if (H2) embed_tile_h2<NX, 0, NY>(a.hpack, lds, a.xc, nullptr, a.C, nullptr, t, npts, a.act, a.group, nt);
-        else embed_tile<NX, 0, NY>(a.hpack, lds, a.xc, nullptr, a.C, nullptr, t, npts, a.act, a.group, nt);
+        if constexpr (MODE == 0) embed_tile<NX, 0, NY>(a.hpack, lds, a.xc, nullptr, a.C, nullptr, t, npts, a.act, a.group, nt);
+        else embed_tile_h2<NX, 0, NY, MODE == 2>(a.hpack, lds, a.xc, nullptr, a.C, nullptr, t, npts, a.act, a.group, nt);
     }
 }
 
-template <int NX, int NU, int NY, bool LOOP, bool H2>
+template <int NX, int NU, int NY, bool LOOP, int MODE>
 static int embed_launch_t(const EmbedArgs& a, const NodeTable& nt, int grid, size_t lds_bytes, hipStream_t stream) {
     static std::atomic<unsigned long long> attr_set{0};
     if (first_use_on_device(attr_set))
-        NMPC_HIP_CHECK(hipFuncSetAttribute((const void*)embed_kernel<NX, NU, NY, LOOP, H2>,
+        NMPC_HIP_CHECK(hipFuncSetAttribute((const void*)embed_kernel<NX, NU, NY, LOOP, MODE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL((embed_kernel<NX, NU, NY, LOOP, H2>), dim3(grid), dim3(EMBED_THREADS), lds_bytes, stream, a, nt);
+    hipLaunchKernelGGL((embed_kernel<NX, NU, NY, LOOP, MODE>), dim3(grid), dim3(EMBED_THREADS), lds_bytes, stream, a, nt);
     NMPC_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -490,12 +510,25 @@ int embed_launch(const ModelDev& m, EmbedArgs a, const NodeTable& nodes, hipStre
     const int grid = a.n_ftiles + (do_h ? tiles : 0);
     const int nout_max = m.nx > m.ny ? m.nx : m.ny;
     const size_t lds_bytes = sizeof(float) * (4096 + 4096 * nout_max + PK_TAIL);
+    // equally spaced nodes within every wave's quarter: step 2^-a by multiplication (NMPC_EMBED_RECUR=0 disables)
+    static int recur_on = -1;
+    if (recur_on < 0) { const char* e = getenv("NMPC_EMBED_RECUR"); recur_on = (e && atoi(e) == 0) ? 0 : 1; }
+    nt.recur = (h2 && recur_on) ? 1 : 0;
+    for (int wv = 0; wv < 4 && nt.recur; ++wv) {
+        const int n0 = (nt.n * wv) >> 2, n1 = (nt.n * (wv + 1)) >> 2;
+        nt.dlam[wv] = n1 - n0 >= 2 ? (float)(((double)nt.lam[n1 - 1] - (double)nt.lam[n0]) / (n1 - n0 - 1)) : 0.0f;
+        for (int i = n0 + 1; i < n1; ++i)      // lam[i] reproduced by lam[n0] + (i - n0) dlam to a few ulp
+            if (std::fabs((double)nt.lam[n0] + (double)(i - n0) * (double)nt.dlam[wv] - (double)nt.lam[i]) > 5e-7) nt.recur = 0;
+    }
+    const int mode = !h2 ? 0 : (nt.recur ? 2 : 1);
 #define NMPC_EMBED_CASE(NX_, NU_, NY_)                                                                   \
     if (m.nx == NX_ && m.nu == NU_ && m.ny == NY_) {                                                     \
-        if (h2) return loop ? embed_launch_t<NX_, NU_, NY_, true, true>(a, nt, grid, lds_bytes, stream)  \
-                            : embed_launch_t<NX_, NU_, NY_, false, true>(a, nt, grid, lds_bytes, stream); \
-        return loop ? embed_launch_t<NX_, NU_, NY_, true, false>(a, nt, grid, lds_bytes, stream)         \
-                    : embed_launch_t<NX_, NU_, NY_, false, false>(a, nt, grid, lds_bytes, stream);       \
+        if (mode == 2) return loop ? embed_launch_t<NX_, NU_, NY_, true, 2>(a, nt, grid, lds_bytes, stream)  \
+                                   : embed_launch_t<NX_, NU_, NY_, false, 2>(a, nt, grid, lds_bytes, stream); \
+        if (mode == 1) return loop ? embed_launch_t<NX_, NU_, NY_, true, 1>(a, nt, grid, lds_bytes, stream)  \
+                                   : embed_launch_t<NX_, NU_, NY_, false, 1>(a, nt, grid, lds_bytes, stream); \
+        return loop ? embed_launch_t<NX_, NU_, NY_, true, 0>(a, nt, grid, lds_bytes, stream)             \
+                    : embed_launch_t<NX_, NU_, NY_, false, 0>(a, nt, grid, lds_bytes, stream);           \
     }
     NMPC_EMBED_CASE(2, 1, 1)
     NMPC_EMBED_CASE(3, 1, 1)
