@@ -123,6 +123,8 @@ def main():
                     help="bracket the kernel launches of every n-th step with HIP event pairs")
     ap.add_argument("--cpu-controllers", type=int, default=12)
     ap.add_argument("--cpu-steps", type=int, default=200)
+    ap.add_argument("--latency-steps", type=int, default=40,
+                    help="single steps run after the timed region for p50_step_latency_ms (0: skip)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="diagnostic: run the N-rank path with every rank on cuda:0 and the gloo backend")
     args = ap.parse_args()
@@ -147,7 +149,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     B, K, W = args.batch, args.steps, args.warmup
-    LAT = 40                                         # extra steps, run one at a time after the timed region
+    LAT = max(0, args.latency_steps)                 # extra steps, run one at a time after the timed region
     nsim = K + W + LAT
     lo = rank * B                                    # global controller ids of this rank
     refs = np.stack([random_level_reference(nsim + NC, [10, 15], [-1, 1], np.random.default_rng(1234 + lo + b))
@@ -191,7 +193,7 @@ def main():
         ctrl.run(k, 1)
         torch.cuda.synchronize(dev)
         lat.append(time.perf_counter() - t1)
-    p50_latency = float(np.median(lat)) * 1e3
+    p50_latency = float(np.median(lat)) * 1e3 if lat else None
     qp_fail, qp_solves, qp_iters = ctrl.stats()
     if qp_fail:
         raise SystemExit("QP failures in the closed loop: result invalid")
