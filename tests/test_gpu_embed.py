@@ -35,6 +35,24 @@ def test_embed_vs_oracle(enc, omodel, P, rule, stages, dlam):
     assert relerr(A.cpu(), Ao) < TOL and relerr(B.cpu(), Bo) < TOL and relerr(C.cpu(), Co) < TOL
 
 
+@pytest.mark.parametrize("n_nodes", [1, 3, 13, 64, 256])
+def test_embed_arbitrary_node_tables(enc, omodel, n_nodes):
+    """Node tables that are not equally spaced (random lambda in (0, 1], random weights, one node at 0 and
+    one of zero weight mixed in): the kernel evaluates every exponential instead of stepping it, orders
+    the nodes by weight and drops what contributes nothing; up to the maximum of 256 nodes."""
+    import nmpc_amd
+    rng = np.random.default_rng(n_nodes)
+    lam = np.sort(rng.uniform(0.02, 1.0, n_nodes)).astype(np.float32); w = rng.uniform(0.1, 1.0, n_nodes).astype(np.float32)
+    if n_nodes >= 13:
+        lam[0] = 0.0; w[5] = 0.0
+    w = (w / w.sum()).astype(np.float32)
+    P = 40
+    x = f32(rng.uniform(-3, 3, (P, 2))); u = f32(rng.uniform(-3, 3, (P, 1))); xc = f32(rng.uniform(-3, 3, (P, 2)))
+    A, B, C = nmpc_amd.embed(enc, torch.tensor(x), torch.tensor(u), torch.tensor(xc), lam, w)
+    Ao, Bo, Co = olpv.embed(omodel, x, u, lam.astype(np.float64), w.astype(np.float64), xc=xc)
+    assert relerr(A.cpu(), Ao) < TOL and relerr(B.cpu(), Bo) < TOL and relerr(C.cpu(), Co) < TOL
+
+
 def test_reference_entry_points_on_golden(enc, golden):
     """lpv_int / lpv_int_C / lambda_simpson / lambda_trap / par_lpv_int with the reference's
     signatures reproduce what the reference's lpv_int.py returned for the same inputs."""
