@@ -213,35 +213,38 @@ __device__ __forceinline__ void embed_tile(const float* __restrict__ pack, float
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void split_pair(float a, float b, unsigned& H, unsigned& L) {
-    // H = the pair truncated to fp16; L = the fp16-rounded remainders a - float(H.lo), b - float(H.hi), each
-    // formed by one mixed-precision fma (fp16 * -1.0 + fp32, exact before the final rounding).
-    H = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
-    unsigned l;
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(H), "v"(a));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(H), "v"(b));
-    L = l;
-}
-
-// 16 fp32 values (unit order) -> B fragments of the two k-steps, high and low planes
+// 16 fp32 values (unit order) -> B fragments of the two k-steps, high and low planes.
+// H = pairs truncated to fp16 (v_cvt_pkrtz); L = the fp16-rounded remainders a - float(H.lo), b - float(H.hi),
+// each formed by one mixed-precision fma (fp16 * -1.0 + fp32, exact before the final rounding).
+// The eight v_fma_mix of a k-step are ONE asm block: the compiler's hazard recognizer does not see
+// instructions inside inline asm, so the distances they need are built in - the write of a register's low
+// half and the read-modify-write of its high half are four instructions apart, and the block ends in the two
+// wait states an MFMA needs after a VALU write of one of its operands (one instantiation read a stale half of
+// a B operand when these were separate statements with an MFMA one instruction behind the last of them).
 __device__ __forceinline__ void split16(const float* v, f16x8* BH, f16x8* BL) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
+        const float* p = v + 8 * ks;
         u32x4 h, l;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            unsigned hh, ll;
-            split_pair(v[8 * ks + 2 * m], v[8 * ks + 2 * m + 1], hh, ll);
-            h[m] = hh; l[m] = ll;
-        }
+        for (int m = 0; m < 4; ++m) h[m] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(p[2 * m], p[2 * m + 1]));
+        unsigned l0, l1, l2, l3;
+        asm("v_fma_mixlo_f16 %0, %4, -1.0, %8 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixlo_f16 %1, %5, -1.0, %10 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixlo_f16 %2, %6, -1.0, %12 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixlo_f16 %3, %7, -1.0, %14 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixhi_f16 %0, %4, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixhi_f16 %1, %5, -1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixhi_f16 %2, %6, -1.0, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixhi_f16 %3, %7, -1.0, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "s_nop 1"
+            : "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
+            : "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]), "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]),
+              "v"(p[6]), "v"(p[7]));
+        l[0] = l0; l[1] = l1; l[2] = l2; l[3] = l3;
         BH[ks] = __builtin_bit_cast(f16x8, h);
         BL[ks] = __builtin_bit_cast(f16x8, l);
     }
-    // The compiler's hazard recognizer does not see the VALU writes made inside inline asm, so the two
-    // wait states an MFMA needs after a VALU write of one of its operands are supplied here, once per
-    // split: every MFMA that takes BH / BL is ordered after this statement.  (Without it one
-    // instantiation read a stale half of a B operand: an MFMA one instruction behind the v_fma_mixhi.)
-    asm volatile("s_nop 1" : "+v"(BH[0]), "+v"(BH[1]), "+v"(BL[0]), "+v"(BL[1]));
 }
 
 // RECUR: the nodes of a wave are equally spaced (nt.dlam): e = 2^-a of layer 1 is stepped from node to
