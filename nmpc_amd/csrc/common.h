@@ -82,6 +82,7 @@ struct ModelDev {
     WideNet wide_f, wide_h;   // both nets for the general-width kernel
     float* wide_slab;         // their storage
     int narrow_ok;            // the 64-wide kernels cover this model's sizes
+    int step_ok;              // layer-1 biases small enough for node-to-node stepping of 2^-a (embed.hip)
     float* enc;     // observer net, plain row-major params concatenated (may be null):
                     // lin_w[out,in] lin_b w0[H,in] b0 w2[H,H] b2 w4[out,H] b4 w2^T[H,H]
     float* hplain;  // h-net in the same plain layout (for the output estimate)

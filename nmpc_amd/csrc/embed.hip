@@ -516,7 +516,7 @@ int embed_launch(const ModelDev& m, EmbedArgs a, const NodeTable& nodes, hipStre
     // equally spaced nodes within every wave's quarter: step 2^-a by multiplication (NMPC_EMBED_RECUR=0 disables)
     static int recur_on = -1;
     if (recur_on < 0) { const char* e = getenv("NMPC_EMBED_RECUR"); recur_on = (e && atoi(e) == 0) ? 0 : 1; }
-    nt.recur = (h2 && recur_on) ? 1 : 0;
+    nt.recur = (h2 && recur_on && m.step_ok) ? 1 : 0;
     for (int wv = 0; wv < 4 && nt.recur; ++wv) {
         const int n0 = (nt.n * wv) >> 2, n1 = (nt.n * (wv + 1)) >> 2;
         nt.dlam[wv] = n1 - n0 >= 2 ? (float)(((double)nt.lam[n1 - 1] - (double)nt.lam[n0]) / (n1 - n0 - 1)) : 0.0f;

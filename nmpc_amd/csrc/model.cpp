@@ -225,6 +225,14 @@ static int model_fill(nmpc_model* m, int nx, int nu, int ny, int hidden, int n_e
     m->d.nx = nx; m->d.nu = nu; m->d.ny = ny; m->d.hidden = hidden; m->d.n_enc_in = enc ? n_enc_in : 0;
     NMPC_HIP_CHECK(hipGetDevice(&m->device));
     m->d.narrow_ok = narrow ? 1 : 0;
+    {   // a = lam g + b0 keeps the sign of g once |lam g| exceeds |b0|, so a unit that has left the range of
+        // fp32's exp2 can only come back if its bias is itself of that size: stepping is enabled for
+        // |c2 b0| <= 32 (tanh arguments up to 11; larger biases pin a unit at +-1 for all sensible inputs)
+        const double c2 = 2.0 * 1.4426950408889634074;
+        double bmax = 0.0;
+        for (int k = 0; k < hidden; ++k) bmax = std::fmax(bmax, std::fmax(std::fabs(c2 * fn[3][k]), std::fabs(c2 * hn[3][k])));
+        m->d.step_ok = bmax <= 32.0 ? 1 : 0;
+    }
     {
         const int ht = hidden <= 64 ? 4 : (hidden <= 128 ? 8 : 16);
         auto padout = [](int n) { return n <= 1 ? 1 : (n <= 4 ? 4 : 8); };

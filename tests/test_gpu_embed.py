@@ -53,6 +53,25 @@ def test_embed_arbitrary_node_tables(enc, omodel, n_nodes):
     assert relerr(A.cpu(), Ao) < TOL and relerr(B.cpu(), Bo) < TOL and relerr(C.cpu(), Co) < TOL
 
 
+def test_embed_far_out_of_range_points(enc, omodel):
+    """Scheduling points thousands of standard deviations out (a diverged loop): pre-activations leave the
+    range in which the kernel may step its exponentials from node to node, so those waves evaluate every
+    node; the result still matches the oracle, and ordinary points in the same launch are unaffected."""
+    import nmpc_amd
+    rng = np.random.default_rng(5)
+    P = 64
+    x = f32(rng.uniform(-3, 3, (P, 2))); u = f32(rng.uniform(-3, 3, (P, 1))); xc = f32(rng.uniform(-3, 3, (P, 2)))
+    x[16:32] *= 400.0; u[16:32] *= 400.0; xc[16:32] *= 400.0          # one tile far out
+    x[40] *= 1500.0; xc[41] *= 1500.0                                   # single points inside ordinary tiles
+    lam, w = nmpc_amd.quad_nodes("simpson", 20)
+    A, B, C = nmpc_amd.embed(enc, torch.tensor(x), torch.tensor(u), torch.tensor(xc), lam, w)
+    Ao, Bo, Co = olpv.embed(omodel, x, u, *olpv.merge_nodes(*olpv.quad_nodes("simpson", 20)), xc=xc)
+    assert torch.isfinite(A).all() and torch.isfinite(B).all() and torch.isfinite(C).all()
+    for got, ref in ((A, Ao), (B, Bo), (C, Co)):
+        err = np.abs(got.cpu().numpy().astype(np.float64).reshape(ref.shape) - ref)
+        assert err.max() / np.abs(ref).max() < TOL
+
+
 def test_reference_entry_points_on_golden(enc, golden):
     """lpv_int / lpv_int_C / lambda_simpson / lambda_trap / par_lpv_int with the reference's
     signatures reproduce what the reference's lpv_int.py returned for the same inputs."""
@@ -145,6 +164,28 @@ def test_synthetic_nets(w2_scale):
         err = np.abs(got.cpu().numpy().astype(np.float64).reshape(ref.shape) - ref).max()
         assert err / np.abs(ref).max() < TOL
     assert relerr(A.cpu(), Ao) < TOL and relerr(C.cpu(), Co) < TOL
+
+
+def test_net_with_huge_bias():
+    """A layer-1 bias of 60 (a unit pinned at +1 unless its input is enormous): such a model does not
+    qualify for stepping the exponentials between nodes, and a point that un-pins the unit within
+    the lambda-range is still integrated like the oracle does."""
+    import nmpc_amd
+    from oracle.model import Model
+    om = Model.synthetic(2, 1, 1, 64, seed=4)
+    om.fn.b0[3] = 60.0; om.hn.b0[7] = -60.0
+    params = {k: [np.asarray(a, np.float32) for a in n.params()] for k, n in (("fn", om.fn), ("hn", om.hn), ("enc", om.enc))}
+    enc = nmpc_amd.Encoder(params, device="cuda:0")
+    rng = np.random.default_rng(2)
+    P = 48
+    x = f32(rng.uniform(-2, 2, (P, 2))); u = f32(rng.uniform(-2, 2, (P, 1))); xc = f32(rng.uniform(-2, 2, (P, 2)))
+    x[:16] *= 60.0; xc[:16] *= 60.0                     # lam * W0 z sweeps through -b0 for some of these
+    lam, w = nmpc_amd.quad_nodes("simpson", 20)
+    A, B, C = nmpc_amd.embed(enc, torch.tensor(x), torch.tensor(u), torch.tensor(xc), lam, w)
+    Ao, Bo, Co = olpv.embed(om, x, u, *olpv.merge_nodes(*olpv.quad_nodes("simpson", 20)), xc=xc)
+    for got, ref in ((A, Ao), (B, Bo), (C, Co)):
+        err = np.abs(got.cpu().numpy().astype(np.float64).reshape(ref.shape) - ref).max()
+        assert err / np.abs(ref).max() < TOL
 
 
 def test_ablist_family_on_golden(enc, golden):
