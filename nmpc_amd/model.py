@@ -65,6 +65,22 @@ class Encoder:
                 pass
             self.handle = None
 
+    @staticmethod
+    def _net_at_zero(p):
+        """W_lin 0 + b_lin + W4 tanh(W2 tanh(b0) + b2) + b4 in fp64 (host; a constant of the model)."""
+        lin_w, lin_b, w0, b0, w2, b2, w4, b4 = [np.asarray(a, np.float64) for a in p]
+        return lin_b + w4 @ np.tanh(w2 @ np.tanh(b0) + b2) + b4
+
+    @property
+    def f0(self):
+        """f(0, 0): the reference's `correction` (NMPC_test.py:38), shape [nx]."""
+        return self._net_at_zero(self.params["fn"])
+
+    @property
+    def h0(self):
+        """h(0): the reference's `correction_h` (NMPC_test.py:41), shape [ny]."""
+        return self._net_at_zero(self.params["hn"])
+
     @classmethod
     def from_npz(cls, path=DISC_WEIGHTS, device=None):
         d = np.load(path)

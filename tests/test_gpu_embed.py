@@ -166,6 +166,12 @@ def test_synthetic_nets(w2_scale):
     assert relerr(A.cpu(), Ao) < TOL and relerr(C.cpu(), Co) < TOL
 
 
+def test_model_offsets(enc, omodel):
+    """Encoder.f0 / Encoder.h0: the reference's `correction` and `correction_h` (NMPC_test.py:38,41)."""
+    assert np.abs(enc.f0 - omodel.f0).max() < 1e-12 and np.abs(enc.h0 - omodel.h0).max() < 1e-12
+    assert enc.f0.shape == (2,) and enc.h0.shape == (1,)
+
+
 def test_net_with_huge_bias():
     """A layer-1 bias of 60 (a unit pinned at +1 unless its input is enormous): such a model does not
     qualify for stepping the exponentials between nodes, and a point that un-pins the unit within
