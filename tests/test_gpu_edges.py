@@ -38,3 +38,35 @@ def test_short_horizons_single_controller(enc, omodel, Nc):
     assert all(torch.equal(before[k], ctrl.logs[k]) for k in before)
     with pytest.raises(nmpc_amd.NmpcError):
         ctrl.run(Nsim, 1)                                # beyond n_sim
+
+
+def test_run_in_pieces_equals_one_run(enc):
+    """nmpc_ctrl_run over [0, Nsim) in one call and in uneven pieces (with the event profiling switched on
+    for one of them) writes bitwise the same logs: the state carried between calls is complete."""
+    import nmpc_amd
+    B, Nc, Nsim = 700, 10, 24
+    refs = np.stack([random_level_reference(Nsim + Nc, [10, 15], [-1, 1], np.random.default_rng(50 + b)) for b in range(B)])
+    nm = enc.norm
+    lam, w = nmpc_amd.quad_nodes("simpson", 20)
+    ymin_n, ymax_n = (-1.2 - nm.y0) / nm.ystd, (1.2 - nm.y0) / nm.ystd
+    umin_n, umax_n = (-4 - nm.u0) / nm.ustd, (4 - nm.u0) / nm.ustd
+    yrn = torch.clamp((torch.as_tensor(refs, device="cuda") - nm.y0) / nm.ystd, ymin_n, ymax_n)
+    Xs, Us, _ = nmpc_amd.getXsUs_Cs(yrn, 2, 1, 1, Nsim + Nc, umin_n, umax_n, [ymin_n], [ymax_n], nmpc_amd.GetABC(enc, lam, w))
+    noise = torch.as_tensor(0.014 * np.random.default_rng(3).standard_normal((Nsim, B)), device="cuda")
+    plant = nmpc_amd.OutputUnbalancedDisc(dt=0.1, sigma_n=[0.014])
+
+    def run(pieces):
+        ctrl = nmpc_amd.Controller(enc, plant, B, Nc, Nsim, 4, Q, 1.0, umin_n, umax_n, ymin_n, ymax_n, lam, w, tol=1e-1, rho=1000.0)
+        ctrl.set_targets(Xs.transpose(1, 2).contiguous(), Us[:, 0, :].contiguous(), noise)
+        ctrl.reset((np.zeros(2) - nm.y0) / nm.ystd, (0 - nm.u0) / nm.ustd)
+        k = 0
+        for i, n in enumerate(pieces):
+            ctrl.profile(1 if i == 1 else 0)
+            ctrl.run(k, n)
+            k += n
+        torch.cuda.synchronize()
+        ctrl.profile_read()
+        return {name: t.clone() for name, t in ctrl.logs.items()}
+    one, many = run([Nsim]), run([1, 7, 0, 11, 5])
+    for name in one:
+        assert torch.equal(one[name], many[name]), name
