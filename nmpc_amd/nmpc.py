@@ -145,6 +145,9 @@ class Controller:
         cfg.dt = float(system.dt)
         for i, v in enumerate(system.params()):
             cfg.plant[i] = float(v)
+        if not 1 <= len(nodes) <= len(cfg.lam) or len(weights) != len(nodes):
+            raise _lib.NmpcError("need 1..%d quadrature nodes with as many weights (got %d, %d)"
+                                 % (len(cfg.lam), len(nodes), len(weights)))
         cfg.n_nodes = len(nodes)
         for i in range(len(nodes)):
             cfg.lam[i] = float(nodes[i]); cfg.w[i] = float(weights[i])
@@ -163,6 +166,7 @@ class Controller:
             rc = lib().nmpc_ctrl_create(ctypes.byref(h), encoder.handle, ctypes.byref(cfg))
         check(rc, "nmpc_ctrl_create")
         self.handle = h
+        self.Xs = self.Us = self.noise = None
         dev = encoder.device
         z = lambda *s, dt=torch.float64: torch.zeros(s, dtype=dt, device=dev)
         B, Ns = self.B, self.Nsim
@@ -195,6 +199,8 @@ class Controller:
         self.noise = None if noise is None else _f64(noise, dev).reshape(shape)
 
     def run(self, k0, nsteps):
+        if self.Xs is None:
+            raise _lib.NmpcError("Controller.run: set_targets() has not been called")
         L = self.logs
         with torch.cuda.device(self.encoder.device):
             rc = lib().nmpc_ctrl_run(self.handle, int(k0), int(nsteps), ptr(self.Xs), ptr(self.Us), ptr(self.noise),

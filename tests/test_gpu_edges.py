@@ -70,3 +70,17 @@ def test_run_in_pieces_equals_one_run(enc):
     one, many = run([Nsim]), run([1, 7, 0, 11, 5])
     for name in one:
         assert torch.equal(one[name], many[name]), name
+
+
+def test_controller_argument_errors(enc):
+    import nmpc_amd
+    plant = nmpc_amd.OutputUnbalancedDisc(dt=0.1, sigma_n=[0.0])
+    lam, w = nmpc_amd.quad_nodes("simpson", 20)
+    mk = lambda lam_, w_: nmpc_amd.Controller(enc, plant, 4, 10, 5, 4, Q, 1.0, -2.0, 2.0, -2.0, 2.0, lam_, w_)
+    with pytest.raises(nmpc_amd.NmpcError):
+        mk(np.linspace(0, 1, 300), np.full(300, 1 / 300))          # more nodes than the library holds
+    with pytest.raises(nmpc_amd.NmpcError):
+        mk(lam, w[:-1])
+    c = mk(lam, w)
+    with pytest.raises(nmpc_amd.NmpcError):
+        c.run(0, 1)                                                  # no targets yet
