@@ -13,8 +13,8 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is
  *     asynchronous on it; no entry point synchronises the device unless stated;
  *   - return value 0 = ok, non-zero = error, message via nmpc_last_error() (thread-local);
- *   - nothing here allocates device memory per call except the *_create functions and the pre-loop
- *     target selectors (which say so);
+ *   - nothing here allocates device memory per call except the *_create functions and the allocating
+ *     forms of the pre-loop target selectors (which say so; their _ws forms take a caller workspace);
  *   - a model or controller handle is used with the device that was current at its creation
  *     current again (one process per GPU needs no care; other callers get an error otherwise).
  */
@@ -126,6 +126,10 @@ typedef struct nmpc_ctrl_config {
     int mode, hard;
     double x_min[4], x_max[4];
     double x_norm0[4], x_normstd[4];
+    /* observer histories (NMPC_test.py:115-118: uhist has encoder.na entries, yhist encoder.nb + 1; the encoder
+     * net reads [uhist, yhist]).  Their sum must equal the model's n_enc_in; 0, 0 = (n_enc_in - 1) / 2 inputs
+     * and the rest outputs. */
+    int n_uhist, n_yhist;
 } nmpc_ctrl_config;
 
 int nmpc_ctrl_create(nmpc_ctrl** out, const nmpc_model* m, const nmpc_ctrl_config* cfg);
@@ -159,27 +163,48 @@ int nmpc_ctrl_profile_read(nmpc_ctrl* c, int* launches, double* total_ms, void* 
 int nmpc_ctrl_profile_read_steps(nmpc_ctrl* c, int k0, int nsteps, double* ms, void* stream);
 
 /* ---- steady-state target selector (reference: mpcUtil.py:241-320 getXsUs_Cs, called pre-loop at
- * NMPC_test.py:79-80).  For every reference sample j, warm-started from sample j-1, iterate up to
- * max_lpv times: embed A,B,C at (xs,us); solve the reference's 4-variable QP
- *   (I-A) xs - B us = f0,  C xs = r_j - h0,  soft input/output box with slack e (weight lam_e);
- * stop when ||xs-xs_old|| <= tol and ||us-us_old|| <= tol.  nu = ny = 1: the nx+1 equalities
- * determine (xs,us) and the QP reduces to e = max(0, worst box violation), which is what is
- * computed.  y_ref_n[nb,nsamp] normalised reference (device fp64).  Outputs (device):
- * Xs[nb,nsamp,nx] Us[nb,nsamp] Es[nb,nsamp] (fp64), iters[nb,nsamp] (int32, may be NULL),
- * status[nb] (int32: 0 ok, 1 singular equality system met).
- * Pre-loop set-up routine: allocates and frees its own workspace and synchronises the stream. */
+ * NMPC_test.py:79-80).  For every reference sample j, warm-started from sample j-1, iterate LPV passes:
+ * embed A,B,C at (xs,us); solve the reference's 4-variable QP
+ *   (I-A) xs - B us = f0,  C xs = r_j - h0,  soft input/output box with slack e (weight lam_e).
+ * nu = ny = 1: the nx+1 equalities determine (xs,us) and the QP reduces to e = max(0, worst box violation),
+ * which is what is computed.
+ * Pass schedule.  max_lpv >= 1: up to max_lpv passes per sample, stop when ||xs-xs_old|| <= tol and
+ * ||us-us_old|| <= tol (the loop as mpcUtil.py:288-313 intends it).  max_lpv = 0: the schedule that code
+ * EXECUTES - xs/us are views of the solution buffer (mpcUtil.py:306-307) which the next solve overwrites
+ * (:302) before xold = np.copy(xs) is taken (:304), so from the second solve on the stop test compares the
+ * solution with itself: sample 0 takes at most two passes, every later sample exactly one, embedded at the
+ * previous sample's target (the same holds for getXsUs, mpcUtil.py:224-233).
+ * y_ref_n[nb,nsamp] normalised reference (device fp64).  Outputs (device): Xs[nb,nsamp,nx] Us[nb,nsamp]
+ * Es[nb,nsamp] (fp64), iters[nb,nsamp] (int32, may be NULL), status[nb] (int32: 0 ok, 1 singular equality
+ * system met).
+ * nmpc_target_select allocates and frees its own workspace and synchronises the stream.  nmpc_target_select_ws
+ * does neither: the caller passes `workspace` (device memory, 16-byte aligned, at least
+ * nmpc_target_workspace_bytes(nx, nb, max_lpv) bytes; contents need not be preserved between calls) and the
+ * whole selection is issued asynchronously on `stream`. */
+unsigned long long nmpc_target_workspace_bytes(int nx, int nb, int max_lpv);
 int nmpc_target_select(const nmpc_model* m, int nb, int nsamp, const double* y_ref_n, double u_min,
                        double u_max, double y_min, double y_max, const float* lam, const float* w,
                        int n_nodes, int max_lpv, double tol, double* Xs, double* Us, double* Es,
                        int* iters, int* status, void* stream);
+int nmpc_target_select_ws(const nmpc_model* m, int nb, int nsamp, const double* y_ref_n, double u_min,
+                          double u_max, double y_min, double y_max, const float* lam, const float* w,
+                          int n_nodes, int max_lpv, double tol, double* Xs, double* Us, double* Es,
+                          int* iters, int* status, void* workspace, unsigned long long workspace_bytes,
+                          void* stream);
 /* State-constrained selector (reference: mpcUtil.py:167-239 getXsUs, called at NMPC.py:541-542): the
  * same iteration with A, B only, a fixed output row C[nx] (host), equality offsets f0[nx] (host; NULL =
- * the model's f(0,0)) and h0, and the soft box -u, u, -xs, xs (x_min[nx], x_max[nx], host, normalised). */
+ * the model's f(0,0)) and h0, and the soft box -u, u, -xs, xs (x_min[nx], x_max[nx], host, normalised).
+ * _ws: caller's workspace, asynchronous, as above. */
 int nmpc_target_select_state(const nmpc_model* m, int nb, int nsamp, const double* y_ref_n, double u_min,
                              double u_max, const double* x_min, const double* x_max, const double* C,
                              const double* f0, double h0, const float* lam, const float* w, int n_nodes,
                              int max_lpv, double tol, double* Xs, double* Us, double* Es, int* iters,
                              int* status, void* stream);
+int nmpc_target_select_state_ws(const nmpc_model* m, int nb, int nsamp, const double* y_ref_n, double u_min,
+                                double u_max, const double* x_min, const double* x_max, const double* C,
+                                const double* f0, double h0, const float* lam, const float* w, int n_nodes,
+                                int max_lpv, double tol, double* Xs, double* Us, double* Es, int* iters,
+                                int* status, void* workspace, unsigned long long workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

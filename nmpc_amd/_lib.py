@@ -44,6 +44,14 @@ SIGNATURES = {
                                                 ctypes.c_double, c_double_p, c_double_p, c_double_p, c_double_p,
                                                 ctypes.c_double, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_double] + [c_void_p] * 6),
+    "nmpc_target_workspace_bytes": (ctypes.c_ulonglong, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "nmpc_target_select_ws": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, c_void_p] + [ctypes.c_double] * 4 +
+                              [c_float_p, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_double] + [c_void_p] * 6 +
+                              [ctypes.c_ulonglong, c_void_p]),
+    "nmpc_target_select_state_ws": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, c_void_p, ctypes.c_double,
+                                                   ctypes.c_double, c_double_p, c_double_p, c_double_p, c_double_p,
+                                                   ctypes.c_double, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int,
+                                                   ctypes.c_double] + [c_void_p] * 6 + [ctypes.c_ulonglong, c_void_p]),
     "nmpc_ctrl_profile": (ctypes.c_int, [c_void_p, ctypes.c_int]),
     "nmpc_ctrl_profile_read": (ctypes.c_int, [c_void_p, c_int_p, c_double_p, c_void_p]),
     "nmpc_ctrl_profile_read_steps": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, c_double_p, c_void_p]),
@@ -65,7 +73,8 @@ class CtrlConfig(ctypes.Structure):
                 ("lam", ctypes.c_float * MAX_NODES), ("w", ctypes.c_float * MAX_NODES),
                 ("mode", ctypes.c_int), ("hard", ctypes.c_int),
                 ("x_min", ctypes.c_double * 4), ("x_max", ctypes.c_double * 4),
-                ("x_norm0", ctypes.c_double * 4), ("x_normstd", ctypes.c_double * 4)]
+                ("x_norm0", ctypes.c_double * 4), ("x_normstd", ctypes.c_double * 4),
+                ("n_uhist", ctypes.c_int), ("n_yhist", ctypes.c_int)]
 
 
 _lib = None

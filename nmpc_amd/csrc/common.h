@@ -13,13 +13,18 @@ namespace nmpc {
 void set_error(const char* fmt, ...);
 
 // hipFuncSetAttribute acts on the current device only: `mask` (one per kernel) remembers the devices
-// on which the attribute has been set.  True the first time it is called on a device.
-inline bool first_use_on_device(std::atomic<unsigned long long>& mask) {
+// on which the attribute has been set.  first_use_on_device is true until mark_used_on_device has been
+// called for the current device - callers set the attribute, then mark; two threads racing here both set
+// the (idempotent) attribute, and neither launches before its own call has returned.
+inline bool first_use_on_device(const std::atomic<unsigned long long>& mask) {
     int dev = 0;
     (void)hipGetDevice(&dev);
-    const unsigned long long bit = 1ull << (dev & 63);
-    if (mask.load(std::memory_order_relaxed) & bit) return false;
-    return (mask.fetch_or(bit) & bit) == 0;
+    return (mask.load(std::memory_order_acquire) & (1ull << (dev & 63))) == 0;
+}
+inline void mark_used_on_device(std::atomic<unsigned long long>& mask) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    mask.fetch_or(1ull << (dev & 63), std::memory_order_release);
 }
 
 // a handle's device memory belongs to the device that was current when it was created

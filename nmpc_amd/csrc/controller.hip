@@ -360,7 +360,16 @@ extern "C" int nmpc_ctrl_create(nmpc_ctrl** out, const nmpc_model* m, const nmpc
     const int B = cfg->batch, Nc = cfg->Nc, nx = m->d.nx;
     d.B = B; d.Nc = Nc; d.nx = nx; d.maxit = cfg->max_iterations; d.n_sim = cfg->n_sim;
     d.n_enc_in = mode ? 1 : m->d.n_enc_in;
-    d.na = (d.n_enc_in - 1) / 2; d.nyh = d.n_enc_in - d.na;        // nb inputs, na+1 outputs (na_right = 1)
+    // observer histories (NMPC_test.py:115-118): n_uhist past inputs then n_yhist past outputs feed the encoder
+    // net; 0/0 in the config means the symmetric split nb = na, outputs = na + 1
+    d.na = cfg->n_uhist; d.nyh = cfg->n_yhist;
+    if (mode == 1) { d.na = 0; d.nyh = 1; }
+    else if (d.na == 0 && d.nyh == 0) { d.na = (d.n_enc_in - 1) / 2; d.nyh = d.n_enc_in - d.na; }
+    if (mode == 0 && (d.na < 0 || d.nyh < 1 || d.na + d.nyh != d.n_enc_in)) {
+        set_error("nmpc_ctrl_create: n_uhist=%d + n_yhist=%d does not match the observer net's %d inputs", d.na, d.nyh, d.n_enc_in);
+        delete c;
+        return 1;
+    }
     d.tol = cfg->tol;
     fill_const(d.c, Nc, nx, cfg->Q, cfg->R, cfg->rho, cfg->u_min, cfg->u_max, cfg->y_min, cfg->y_max, m->d.f0, m->d.h0[0]);
     if (mode == 1) {   // the state-feedback controllers drop the model offset (rhs_c, NMPC.py:387,520)
@@ -370,8 +379,12 @@ extern "C" int nmpc_ctrl_create(nmpc_ctrl** out, const nmpc_model* m, const nmpc
     d.u0 = cfg->u0; d.ustd = cfg->ustd; d.y0 = cfg->y0; d.ystd = cfg->ystd; d.dt = cfg->dt;
     for (int i = 0; i < 6; ++i) d.plant[i] = cfg->plant[i];
     d.enc = m->d.enc; d.hplain = m->d.hplain;
-    c->nt.n = cfg->n_nodes;
-    for (int i = 0; i < NMPC_MAX_NODES; ++i) { c->nt.lam[i] = i < cfg->n_nodes ? cfg->lam[i] : 0.f; c->nt.w[i] = i < cfg->n_nodes ? cfg->w[i] : 0.f; }
+    {   // the node table every embedding launch of this controller uses, prepared once
+        NodeTable raw;
+        raw.n = cfg->n_nodes;
+        for (int i = 0; i < NMPC_MAX_NODES; ++i) { raw.lam[i] = i < cfg->n_nodes ? cfg->lam[i] : 0.f; raw.w[i] = i < cfg->n_nodes ? cfg->w[i] : 0.f; }
+        if (embed_prepare_nodes(c->m, raw, c->nt)) { delete c; return 1; }
+    }
     auto alloc = [&](void** p, size_t bytes) -> int {
         NMPC_HIP_CHECK(hipMalloc(p, bytes));
         NMPC_HIP_CHECK(hipMemset(*p, 0, bytes));
@@ -502,7 +515,7 @@ extern "C" int nmpc_ctrl_run(nmpc_ctrl* c, int k0, int nsteps, const double* Xs,
                 if (it > 0) { a.count_dev = d.nact + it; a.act = d.act + (size_t)it * d.B; }
                 ProfRec pr;
                 bool on = prof_begin(c, 0, k, s, pr);
-                if (embed_launch(c->m, a, c->nt, s, true)) return 1;
+                if (embed_launch_prepared(c->m, a, c->nt, s, true)) return 1;
                 prof_end(c, on, s, pr);
                 on = prof_begin(c, 1, k, s, pr);
                 if (dispatch_mpc_solve(d, rp, it, k, c->g, s)) return 1;

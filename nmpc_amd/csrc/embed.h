@@ -21,6 +21,7 @@ struct NodeTable {
     // multiplication instead of evaluating it)
     int recur;
     float dlam[4];
+    int prepared;   // set by embed_prepare_nodes
 };
 
 struct EmbedArgs {
@@ -40,6 +41,10 @@ struct EmbedArgs {
 };
 
 int embed_launch(const ModelDev& m, EmbedArgs a, const NodeTable& nt, hipStream_t stream, bool loop = false);
+// The node table a launch uses (lambda = 0 nodes folded, equal weights adjacent, stepping data) depends only
+// on the model and the caller's nodes: callers that launch repeatedly prepare it once.
+int embed_prepare_nodes(const ModelDev& m, const NodeTable& nodes, NodeTable& prepared);
+int embed_launch_prepared(const ModelDev& m, EmbedArgs a, const NodeTable& prepared, hipStream_t stream, bool loop = false);
 // general-width kernel (embed_wide.hip); nt must already have its lambda = 0 nodes folded into w_zero
 int embed_wide_launch(const ModelDev& m, const EmbedArgs& a, const NodeTable& nt, hipStream_t stream, bool loop);
 

@@ -461,9 +461,11 @@ __global__ __launch_bounds__(EMBED_THREADS, 3) void embed_kernel(EmbedArgs a, No
 template <int NX, int NU, int NY, bool LOOP, int MODE>
 static int embed_launch_t(const EmbedArgs& a, const NodeTable& nt, int grid, size_t lds_bytes, hipStream_t stream) {
     static std::atomic<unsigned long long> attr_set{0};
-    if (first_use_on_device(attr_set))
+    if (first_use_on_device(attr_set)) {
         NMPC_HIP_CHECK(hipFuncSetAttribute((const void*)embed_kernel<NX, NU, NY, LOOP, MODE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        mark_used_on_device(attr_set);
+    }
     hipLaunchKernelGGL((embed_kernel<NX, NU, NY, LOOP, MODE>), dim3(grid), dim3(EMBED_THREADS), lds_bytes, stream, a, nt);
     NMPC_HIP_CHECK(hipGetLastError());
     return 0;
@@ -472,18 +474,28 @@ static int embed_launch_t(const EmbedArgs& a, const NodeTable& nt, int grid, siz
 // NMPC_EMBED=f32 selects the fp32-MFMA kernel, NMPC_EMBED=wide the general-width kernel, anything else
 // the split-fp16 kernel (when the model's weights suit it: see pack_net_h2)
 static int embed_mode() {
-    static int v = -1;
+    static std::atomic<int> cache{-1};
+    int v = cache.load(std::memory_order_relaxed);
     if (v < 0) {
         const char* e = getenv("NMPC_EMBED");
         v = (e && std::string(e) == "f32") ? 0 : ((e && std::string(e) == "wide") ? 2 : 1);
+        cache.store(v, std::memory_order_relaxed);
     }
     return v;
 }
 static bool embed_use_h2() { return embed_mode() == 1; }
 
-int embed_launch(const ModelDev& m, EmbedArgs a, const NodeTable& nodes, hipStream_t stream, bool loop) {
+// equally spaced nodes within every wave's quarter: 2^-a is stepped by multiplication (NMPC_EMBED_RECUR=0 disables)
+static bool recur_enabled() {
+    static std::atomic<int> v{-1};
+    int r = v.load(std::memory_order_relaxed);
+    if (r < 0) { const char* e = getenv("NMPC_EMBED_RECUR"); r = (e && atoi(e) == 0) ? 0 : 1; v.store(r, std::memory_order_relaxed); }
+    return r == 1;
+}
+
+int embed_prepare_nodes(const ModelDev& m, const NodeTable& nodes, NodeTable& nt) {
     NMPC_REQUIRE(nodes.n >= 1 && nodes.n <= NMPC_MAX_NODES, "embed: node count %d out of range", nodes.n);
-    NodeTable nt{};
+    nt = NodeTable{};
     for (int i = 0; i < nodes.n; ++i) {
         nt.w_sum += nodes.w[i];
         if (nodes.lam[i] == 0.0f) { nt.w_zero += nodes.w[i]; continue; }
@@ -499,6 +511,26 @@ int embed_launch(const ModelDev& m, EmbedArgs a, const NodeTable& nodes, hipStre
         for (int i = 0; i < nt.n; ++i) { sorted.lam[i] = nt.lam[idx[i]]; sorted.w[i] = nt.w[idx[i]]; }
         nt = sorted;
     }
+    const bool h2 = m.narrow_ok && embed_use_h2() && m.fpack_h2 && m.hpack_h2;
+    nt.recur = (h2 && recur_enabled() && m.step_ok) ? 1 : 0;
+    for (int wv = 0; wv < 4 && nt.recur; ++wv) {
+        const int n0 = (nt.n * wv) >> 2, n1 = (nt.n * (wv + 1)) >> 2;
+        nt.dlam[wv] = n1 - n0 >= 2 ? (float)(((double)nt.lam[n1 - 1] - (double)nt.lam[n0]) / (n1 - n0 - 1)) : 0.0f;
+        for (int i = n0 + 1; i < n1; ++i)      // lam[i] reproduced by lam[n0] + (i - n0) dlam to a few ulp
+            if (std::fabs((double)nt.lam[n0] + (double)(i - n0) * (double)nt.dlam[wv] - (double)nt.lam[i]) > 5e-7) nt.recur = 0;
+    }
+    nt.prepared = 1;
+    return 0;
+}
+
+int embed_launch(const ModelDev& m, EmbedArgs a, const NodeTable& nodes, hipStream_t stream, bool loop) {
+    NodeTable nt;
+    if (embed_prepare_nodes(m, nodes, nt)) return 1;
+    return embed_launch_prepared(m, a, nt, stream, loop);
+}
+
+int embed_launch_prepared(const ModelDev& m, EmbedArgs a, const NodeTable& nt, hipStream_t stream, bool loop) {
+    NMPC_REQUIRE(nt.prepared == 1, "embed: node table not prepared");
     NMPC_REQUIRE(a.npts >= 0, "embed: negative point count");
     if (a.npts == 0) return 0;
     const bool do_f = a.x && a.u && a.A && a.B, do_h = a.xc && a.C;
@@ -509,20 +541,9 @@ int embed_launch(const ModelDev& m, EmbedArgs a, const NodeTable& nodes, hipStre
     const bool h2 = embed_use_h2() && m.fpack_h2 && m.hpack_h2;
     a.fpack = h2 ? m.fpack_h2 : m.fpack; a.hpack = h2 ? m.hpack_h2 : m.hpack;
     a.n_ftiles = do_f ? tiles : 0;
-    if (a.group < 1) a.group = 1;
     const int grid = a.n_ftiles + (do_h ? tiles : 0);
     const int nout_max = m.nx > m.ny ? m.nx : m.ny;
     const size_t lds_bytes = sizeof(float) * (4096 + 4096 * nout_max + PK_TAIL);
-    // equally spaced nodes within every wave's quarter: step 2^-a by multiplication (NMPC_EMBED_RECUR=0 disables)
-    static int recur_on = -1;
-    if (recur_on < 0) { const char* e = getenv("NMPC_EMBED_RECUR"); recur_on = (e && atoi(e) == 0) ? 0 : 1; }
-    nt.recur = (h2 && recur_on && m.step_ok) ? 1 : 0;
-    for (int wv = 0; wv < 4 && nt.recur; ++wv) {
-        const int n0 = (nt.n * wv) >> 2, n1 = (nt.n * (wv + 1)) >> 2;
-        nt.dlam[wv] = n1 - n0 >= 2 ? (float)(((double)nt.lam[n1 - 1] - (double)nt.lam[n0]) / (n1 - n0 - 1)) : 0.0f;
-        for (int i = n0 + 1; i < n1; ++i)      // lam[i] reproduced by lam[n0] + (i - n0) dlam to a few ulp
-            if (std::fabs((double)nt.lam[n0] + (double)(i - n0) * (double)nt.dlam[wv] - (double)nt.lam[i]) > 5e-7) nt.recur = 0;
-    }
     const int mode = !h2 ? 0 : (nt.recur ? 2 : 1);
 #define NMPC_EMBED_CASE(NX_, NU_, NY_)                                                                   \
     if (m.nx == NX_ && m.nu == NU_ && m.ny == NY_) {                                                     \

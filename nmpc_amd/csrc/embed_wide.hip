@@ -192,6 +192,7 @@ static int wide_launch_t(const WideArgs& a, const NodeTable& nt, int grid, hipSt
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         NMPC_HIP_CHECK(hipFuncSetAttribute((const void*)embed_wide_kernel<HT, NOUT, true>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        mark_used_on_device(once);
     }
     if (loop) hipLaunchKernelGGL((embed_wide_kernel<HT, NOUT, true>), dim3(grid), dim3(256), lds, s, a, nt);
     else hipLaunchKernelGGL((embed_wide_kernel<HT, NOUT, false>), dim3(grid), dim3(256), lds, s, a, nt);

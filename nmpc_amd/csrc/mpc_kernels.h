@@ -432,7 +432,10 @@ static int set_lds_attr(K kernel) {
 template <int GS, int MPL, int NX, int NC = 0>
 static int launch_mpc_qp(const MpcQpArgs& a, const MpcGeom& g, hipStream_t s) {
     static std::atomic<unsigned long long> once{0};
-    if (first_use_on_device(once) && set_lds_attr(mpc_qp_kernel<GS, MPL, NX, NC>)) return 1;
+    if (first_use_on_device(once)) {
+        if (set_lds_attr(mpc_qp_kernel<GS, MPL, NX, NC>)) return 1;
+        mark_used_on_device(once);
+    }
     hipLaunchKernelGGL((mpc_qp_kernel<GS, MPL, NX, NC>), dim3((a.nb + g.gpb - 1) / g.gpb), dim3(g.gpb * GS), g.lds, s, a);
     NMPC_HIP_CHECK(hipGetLastError());
     return 0;
@@ -441,7 +444,10 @@ static int launch_mpc_qp(const MpcQpArgs& a, const MpcGeom& g, hipStream_t s) {
 template <int GS, int MPL, int NX, int NC = 0>
 static int launch_mpc_solve(const CtrlDev& d, const RunPtrs& rp, int it, int k, const MpcGeom& g, hipStream_t s) {
     static std::atomic<unsigned long long> once{0};
-    if (first_use_on_device(once) && set_lds_attr(mpc_solve_kernel<GS, MPL, NX, NC>)) return 1;
+    if (first_use_on_device(once)) {
+        if (set_lds_attr(mpc_solve_kernel<GS, MPL, NX, NC>)) return 1;
+        mark_used_on_device(once);
+    }
     hipLaunchKernelGGL((mpc_solve_kernel<GS, MPL, NX, NC>), dim3((d.B + g.gpb - 1) / g.gpb), dim3(g.gpb * GS), g.lds, s, d, rp, it, k);
     NMPC_HIP_CHECK(hipGetLastError());
     return 0;

@@ -55,9 +55,11 @@ __global__ void qp_kernel(QPArgs a) {
 template <int GS, int MPL>
 static int qp_launch_t(const QPArgs& a, int gpb, size_t lds_bytes, hipStream_t stream) {
     static std::atomic<unsigned long long> attr_set{0};
-    if (first_use_on_device(attr_set))
+    if (first_use_on_device(attr_set)) {
         NMPC_HIP_CHECK(hipFuncSetAttribute((const void*)qp_kernel<GS, MPL>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        mark_used_on_device(attr_set);
+    }
     const int grid = (a.nb + gpb - 1) / gpb;
     hipLaunchKernelGGL((qp_kernel<GS, MPL>), dim3(grid), dim3(gpb * GS), lds_bytes, stream, a);
     NMPC_HIP_CHECK(hipGetLastError());

@@ -122,47 +122,66 @@ __global__ void target_kernel(TargetArgs a, int j, int i) {
 
 using namespace nmpc;
 
-static int target_run(const nmpc_model* m, TargetArgs a, const float* lam, const float* w, int n_nodes, void* stream) {
-    hipStream_t s = (hipStream_t)stream;
-    const int nx = m->d.nx, nb = a.nb, nsamp = a.nsamp, max_lpv = a.max_lpv;
-    int* status = a.status;
-    NodeTable nt;
-    nt.n = n_nodes;
-    for (int i = 0; i < NMPC_MAX_NODES; ++i) { nt.lam[i] = i < n_nodes ? lam[i] : 0.f; nt.w[i] = i < n_nodes ? w[i] : 0.f; }
-    // one slab: xs, us (fp64) | xs32 us32 A32 B32 C32 (fp32) | act[2][nb], counts[max_lpv+1] (int)
+// workspace of one call: xs, us (fp64) | xs32 us32 A32 B32 C32 (fp32) | act[2][nb], counts[max passes + 2] (int)
+static size_t target_ws_bytes(int nx, int nb, int max_lpv) {
     const size_t nB = (size_t)nb;
-    const size_t bytes = nB * (nx + 1) * 8 + nB * (size_t)(nx + 1 + nx * nx + nx + nx) * 4 + (2 * nB + max_lpv + 2) * 4;
-    char* slab = nullptr;
-    NMPC_HIP_CHECK(hipMalloc((void**)&slab, bytes));
-    hipError_t e0 = hipMemsetAsync(slab, 0, bytes, s);
-    if (e0 != hipSuccess) { (void)hipFree(slab); set_error("nmpc_target_select: memset failed"); return 1; }
-    char* p = slab;
+    const int passes = max_lpv > 0 ? max_lpv : 2;
+    size_t bytes = nB * (nx + 1) * 8 + nB * (size_t)(nx + 1 + nx * nx + nx + nx) * 4 + (2 * nB + passes + 2) * 4;
+    return (bytes + 255) & ~(size_t)255;
+}
+
+// Issues the whole selection on `stream` into the caller's workspace `ws` (target_ws_bytes, 16-byte aligned);
+// allocates nothing and does not synchronise.  max_lpv = 0 selects the pass schedule the reference's code
+// executes (see nmpc_target_select in the header): at most two passes for sample 0, one for every later sample.
+static int target_issue(const nmpc_model* m, TargetArgs a, const float* lam, const float* w, int n_nodes, char* ws,
+                        void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const int nx = m->d.nx, nb = a.nb, nsamp = a.nsamp;
+    const bool as_executed = a.max_lpv == 0;
+    const int max_passes = as_executed ? 2 : a.max_lpv;
+    NodeTable raw, nt;
+    raw.n = n_nodes;
+    for (int i = 0; i < NMPC_MAX_NODES; ++i) { raw.lam[i] = i < n_nodes ? lam[i] : 0.f; raw.w[i] = i < n_nodes ? w[i] : 0.f; }
+    if (embed_prepare_nodes(m->d, raw, nt)) return 1;
+    const size_t nB = (size_t)nb;
+    NMPC_HIP_CHECK(hipMemsetAsync(ws, 0, target_ws_bytes(nx, nb, a.max_lpv), s));
+    char* p = ws;
     a.xs = (double*)p; p += nB * nx * 8; a.us = (double*)p; p += nB * 8;
     a.xs32 = (float*)p; p += nB * nx * 4; a.us32 = (float*)p; p += nB * 4;
     a.A32 = (float*)p; p += nB * nx * nx * 4; a.B32 = (float*)p; p += nB * nx * 4; a.C32 = (float*)p; p += nB * nx * 4;
     a.act = (int*)p; p += 2 * nB * 4; a.counts = (int*)p;
-    int rc = 0;
-    if (hipMemsetAsync(status, 0, nB * 4, s) != hipSuccess) { (void)hipFree(slab); set_error("nmpc_target_select: memset failed"); return 1; }
+    NMPC_HIP_CHECK(hipMemsetAsync(a.status, 0, nB * 4, s));
     const int threads = 64, grid = (nb + threads - 1) / threads;
-    for (int j = 0; j < nsamp && !rc; ++j) {
-        if (hipMemsetAsync(a.counts, 0, (max_lpv + 1) * 4, s) != hipSuccess) { rc = 1; break; }
-        for (int i = 0; i < max_lpv && !rc; ++i) {
+    for (int j = 0; j < nsamp; ++j) {
+        const int lim = as_executed ? (j == 0 ? 2 : 1) : max_passes;
+        a.max_lpv = lim;
+        if (lim > 1) NMPC_HIP_CHECK(hipMemsetAsync(a.counts, 0, (lim + 1) * 4, s));
+        for (int i = 0; i < lim; ++i) {
             EmbedArgs ea{};
             ea.x = a.xs32; ea.u = a.us32; ea.A = a.A32; ea.B = a.B32;
             if (!a.state) { ea.xc = a.xs32; ea.C = a.C32; }
             ea.npts = nb; ea.group = 1;
             if (i > 0) { ea.count_dev = a.counts + i; ea.act = a.act + (size_t)(i & 1) * nb; }
-            rc = embed_launch(m->d, ea, nt, s);
-            if (rc) break;
+            if (embed_launch_prepared(m->d, ea, nt, s, false)) return 1;
             switch (nx) {
 #define NMPC_TARGET_CASE(NX_) case NX_: hipLaunchKernelGGL((target_kernel<NX_>), dim3(grid), dim3(threads), 0, s, a, j, i); break;
                 NMPC_TARGET_CASE(1) NMPC_TARGET_CASE(2) NMPC_TARGET_CASE(3) NMPC_TARGET_CASE(4)
                 NMPC_TARGET_CASE(5) NMPC_TARGET_CASE(6) NMPC_TARGET_CASE(7) NMPC_TARGET_CASE(8)
 #undef NMPC_TARGET_CASE
-                default: set_error("nmpc_target_select: nx=%d unsupported (1..8)", nx); rc = 1;
+                default: set_error("nmpc_target_select: nx=%d unsupported (1..8)", nx); return 1;
             }
+            NMPC_HIP_CHECK(hipGetLastError());
         }
     }
+    return 0;
+}
+
+// allocating form: own workspace, synchronises before freeing it
+static int target_run(const nmpc_model* m, const TargetArgs& a, const float* lam, const float* w, int n_nodes, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    char* slab = nullptr;
+    NMPC_HIP_CHECK(hipMalloc((void**)&slab, target_ws_bytes(m->d.nx, a.nb, a.max_lpv)));
+    const int rc = target_issue(m, a, lam, w, n_nodes, slab, stream);
     hipError_t e1 = hipStreamSynchronize(s);
     hipError_t e2 = hipGetLastError();
     (void)hipFree(slab);
@@ -171,35 +190,33 @@ static int target_run(const nmpc_model* m, TargetArgs a, const float* lam, const
     return 0;
 }
 
-extern "C" int nmpc_target_select(const nmpc_model* m, int nb, int nsamp, const double* y_ref_n, double u_min,
-                                  double u_max, double y_min, double y_max, const float* lam, const float* w,
-                                  int n_nodes, int max_lpv, double tol, double* Xs, double* Us, double* Es,
-                                  int* iters, int* status, void* stream) {
+static int target_fill_output(const nmpc_model* m, TargetArgs& a, int nb, int nsamp, const double* y_ref_n, double u_min,
+                              double u_max, double y_min, double y_max, const float* lam, const float* w, int n_nodes,
+                              int max_lpv, double tol, double* Xs, double* Us, double* Es, int* iters, int* status) {
     NMPC_REQUIRE(m && y_ref_n && lam && w && Xs && Us && Es && status, "nmpc_target_select: null argument");
     NMPC_REQUIRE(on_device(m->device), "nmpc_target_select: the model lives on device %d, which is not the current device", m->device);
     NMPC_REQUIRE(m->d.nu == 1 && m->d.ny == 1, "nmpc_target_select: needs nu = ny = 1 (as the reference)");
-    NMPC_REQUIRE(nb >= 1 && nsamp >= 1 && max_lpv >= 1 && max_lpv <= 1024, "nmpc_target_select: bad sizes");
+    NMPC_REQUIRE(nb >= 1 && nsamp >= 1 && max_lpv >= 0 && max_lpv <= 1024, "nmpc_target_select: bad sizes");
     NMPC_REQUIRE(n_nodes >= 1 && n_nodes <= NMPC_MAX_NODES, "nmpc_target_select: bad node count");
-    TargetArgs a{};
+    a = TargetArgs{};
     a.nb = nb; a.nsamp = nsamp; a.max_lpv = max_lpv; a.tol = tol;
     a.umin = u_min; a.umax = u_max; a.ymin = y_min; a.ymax = y_max; a.h0 = m->d.h0[0];
     for (int r = 0; r < m->d.nx; ++r) a.f0[r] = m->d.f0[r];
     a.yref = y_ref_n; a.Xs = Xs; a.Us = Us; a.Es = Es; a.iters = iters; a.status = status;
-    return target_run(m, a, lam, w, n_nodes, stream);
+    return 0;
 }
 
-extern "C" int nmpc_target_select_state(const nmpc_model* m, int nb, int nsamp, const double* y_ref_n, double u_min,
-                                        double u_max, const double* x_min, const double* x_max, const double* C,
-                                        const double* f0, double h0, const float* lam, const float* w, int n_nodes,
-                                        int max_lpv, double tol, double* Xs, double* Us, double* Es, int* iters,
-                                        int* status, void* stream) {
+static int target_fill_state(const nmpc_model* m, TargetArgs& a, int nb, int nsamp, const double* y_ref_n, double u_min,
+                             double u_max, const double* x_min, const double* x_max, const double* C, const double* f0,
+                             double h0, const float* lam, const float* w, int n_nodes, int max_lpv, double tol, double* Xs,
+                             double* Us, double* Es, int* iters, int* status) {
     NMPC_REQUIRE(m && y_ref_n && x_min && x_max && C && lam && w && Xs && Us && Es && status,
                  "nmpc_target_select_state: null argument");
     NMPC_REQUIRE(on_device(m->device), "nmpc_target_select_state: the model lives on device %d, which is not the current device", m->device);
     NMPC_REQUIRE(m->d.nu == 1, "nmpc_target_select_state: needs nu = 1 and one output row (as the reference)");
-    NMPC_REQUIRE(nb >= 1 && nsamp >= 1 && max_lpv >= 1 && max_lpv <= 1024, "nmpc_target_select_state: bad sizes");
+    NMPC_REQUIRE(nb >= 1 && nsamp >= 1 && max_lpv >= 0 && max_lpv <= 1024, "nmpc_target_select_state: bad sizes");
     NMPC_REQUIRE(n_nodes >= 1 && n_nodes <= NMPC_MAX_NODES, "nmpc_target_select_state: bad node count");
-    TargetArgs a{};
+    a = TargetArgs{};
     a.nb = nb; a.nsamp = nsamp; a.max_lpv = max_lpv; a.tol = tol;
     a.umin = u_min; a.umax = u_max; a.h0 = h0; a.state = 1;
     for (int r = 0; r < m->d.nx; ++r) {
@@ -207,5 +224,63 @@ extern "C" int nmpc_target_select_state(const nmpc_model* m, int nb, int nsamp, 
         a.Cfix[r] = C[r]; a.xmin[r] = x_min[r]; a.xmax[r] = x_max[r];
     }
     a.yref = y_ref_n; a.Xs = Xs; a.Us = Us; a.Es = Es; a.iters = iters; a.status = status;
+    return 0;
+}
+
+static int target_check_ws(const nmpc_model* m, const TargetArgs& a, const void* ws, unsigned long long ws_bytes) {
+    NMPC_REQUIRE(ws && ((size_t)ws & 15) == 0, "nmpc_target_select: workspace must be a 16-byte aligned device pointer");
+    const size_t need = target_ws_bytes(m->d.nx, a.nb, a.max_lpv);
+    NMPC_REQUIRE(ws_bytes >= need, "nmpc_target_select: workspace of %llu bytes is too small (%zu needed)", ws_bytes, need);
+    return 0;
+}
+
+extern "C" unsigned long long nmpc_target_workspace_bytes(int nx, int nb, int max_lpv) {
+    if (nx < 1 || nb < 1 || max_lpv < 0) return 0;
+    return (unsigned long long)target_ws_bytes(nx, nb, max_lpv);
+}
+
+extern "C" int nmpc_target_select(const nmpc_model* m, int nb, int nsamp, const double* y_ref_n, double u_min,
+                                  double u_max, double y_min, double y_max, const float* lam, const float* w,
+                                  int n_nodes, int max_lpv, double tol, double* Xs, double* Us, double* Es,
+                                  int* iters, int* status, void* stream) {
+    TargetArgs a;
+    if (target_fill_output(m, a, nb, nsamp, y_ref_n, u_min, u_max, y_min, y_max, lam, w, n_nodes, max_lpv, tol, Xs, Us, Es,
+                           iters, status)) return 1;
     return target_run(m, a, lam, w, n_nodes, stream);
+}
+
+extern "C" int nmpc_target_select_ws(const nmpc_model* m, int nb, int nsamp, const double* y_ref_n, double u_min,
+                                     double u_max, double y_min, double y_max, const float* lam, const float* w,
+                                     int n_nodes, int max_lpv, double tol, double* Xs, double* Us, double* Es,
+                                     int* iters, int* status, void* workspace, unsigned long long workspace_bytes,
+                                     void* stream) {
+    TargetArgs a;
+    if (target_fill_output(m, a, nb, nsamp, y_ref_n, u_min, u_max, y_min, y_max, lam, w, n_nodes, max_lpv, tol, Xs, Us, Es,
+                           iters, status)) return 1;
+    if (target_check_ws(m, a, workspace, workspace_bytes)) return 1;
+    return target_issue(m, a, lam, w, n_nodes, (char*)workspace, stream);
+}
+
+extern "C" int nmpc_target_select_state(const nmpc_model* m, int nb, int nsamp, const double* y_ref_n, double u_min,
+                                        double u_max, const double* x_min, const double* x_max, const double* C,
+                                        const double* f0, double h0, const float* lam, const float* w, int n_nodes,
+                                        int max_lpv, double tol, double* Xs, double* Us, double* Es, int* iters,
+                                        int* status, void* stream) {
+    TargetArgs a;
+    if (target_fill_state(m, a, nb, nsamp, y_ref_n, u_min, u_max, x_min, x_max, C, f0, h0, lam, w, n_nodes, max_lpv, tol, Xs,
+                          Us, Es, iters, status)) return 1;
+    return target_run(m, a, lam, w, n_nodes, stream);
+}
+
+extern "C" int nmpc_target_select_state_ws(const nmpc_model* m, int nb, int nsamp, const double* y_ref_n, double u_min,
+                                           double u_max, const double* x_min, const double* x_max, const double* C,
+                                           const double* f0, double h0, const float* lam, const float* w, int n_nodes,
+                                           int max_lpv, double tol, double* Xs, double* Us, double* Es, int* iters,
+                                           int* status, void* workspace, unsigned long long workspace_bytes,
+                                           void* stream) {
+    TargetArgs a;
+    if (target_fill_state(m, a, nb, nsamp, y_ref_n, u_min, u_max, x_min, x_max, C, f0, h0, lam, w, n_nodes, max_lpv, tol, Xs,
+                          Us, Es, iters, status)) return 1;
+    if (target_check_ws(m, a, workspace, workspace_bytes)) return 1;
+    return target_issue(m, a, lam, w, n_nodes, (char*)workspace, stream);
 }

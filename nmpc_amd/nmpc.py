@@ -152,6 +152,8 @@ class Controller:
         for i in range(len(nodes)):
             cfg.lam[i] = float(nodes[i]); cfg.w[i] = float(weights[i])
         self.state_feedback = state_feedback is not None
+        if state_feedback is None:           # NMPC_test.py:115-118: uhist has encoder.na entries, yhist encoder.nb + 1
+            cfg.n_uhist, cfg.n_yhist = int(encoder.na), int(encoder.nb) + 1
         if state_feedback is not None:
             cfg.mode, cfg.hard = 1, int(bool(state_feedback.get("hard", False)))
             for i in range(encoder.nx):

@@ -70,6 +70,40 @@ def embed(model, x, u, nodes, weights, xc=None):
     return A, B, C
 
 
+def embed_functorch(model, x, u, nodes, weights, xc=None):
+    """The same A, B, C with the Jacobians taken by torch.func.vmap(jacrev(.)) on the CPU, the
+    mechanism of the reference's batched variant (NMPC_test.py:129-146, 176-177): one row per
+    (scheduling point, node), fp64, then the weighted sums.  Used by the CPU baseline and to
+    cross-check the analytic Jacobians."""
+    import torch
+    from torch.func import jacrev, vmap
+    if not hasattr(model, "_torch_nets"):
+        t = lambda a: torch.as_tensor(np.asarray(a, np.float64))
+
+        def make(net):
+            lw, lb, w0, b0, w2, b2, w4, b4 = (t(a) for a in net.params())
+            return lambda z: lw @ z + lb + w4 @ torch.tanh(w2 @ torch.tanh(w0 @ z + b0) + b2) + b4
+        fz, hz = make(model.fn), make(model.hn)
+        model._torch_nets = (vmap(jacrev(lambda xx, uu: fz(torch.cat([xx, uu])), argnums=(0, 1))), vmap(jacrev(hz)))
+    JacF, JacH = model._torch_nets
+    x = np.asarray(x, np.float64); u = np.asarray(u, np.float64)
+    xc = x if xc is None else np.asarray(xc, np.float64)
+    nx, nu, ny = model.nx, model.nu, model.ny
+    lead = x.shape[:-1]
+    X = x.reshape(-1, nx); U = u.reshape(-1, nu); XC = xc.reshape(-1, nx)
+    lam = torch.as_tensor(np.asarray(nodes, np.float64)); wt = torch.as_tensor(np.asarray(weights, np.float64))
+    P, S = X.shape[0], lam.numel()
+    xt = (torch.as_tensor(X)[:, None, :] * lam[None, :, None]).reshape(P * S, nx)
+    ut = (torch.as_tensor(U)[:, None, :] * lam[None, :, None]).reshape(P * S, nu)
+    ct = (torch.as_tensor(XC)[:, None, :] * lam[None, :, None]).reshape(P * S, nx)
+    fA, fB = JacF(xt, ut)
+    fC = JacH(ct)
+    A = (fA.reshape(P, S, nx, nx) * wt[None, :, None, None]).sum(1).numpy().reshape(lead + (nx, nx))
+    B = (fB.reshape(P, S, nx, nu) * wt[None, :, None, None]).sum(1).numpy().reshape(lead + (nx, nu))
+    C = (fC.reshape(P, S, ny, nx) * wt[None, :, None, None]).sum(1).numpy().reshape(xc.shape[:-1] + (ny, nx))
+    return A, B, C
+
+
 # --- reference-named entry points (numeric x, u; Jacobians as callables) ---------------
 def _rule(x, u, Jfx, Jfu, Jhx, nodes, weights):
     x = np.asarray(x, np.float64); u = np.asarray(u, np.float64)

@@ -10,7 +10,14 @@ kept:
            - one scalar slack on every constraint row, input rows included, free sign
              (NMPC_test.py:223-226);
            - target-selector inequality right-hand side without the h0 shift: the
-             (4,1)-(4,) broadcast at mpcUtil.py:254 followed by h[:,0] at :302 drops it.
+             (4,1)-(4,) broadcast at mpcUtil.py:254 followed by h[:,0] at :302 drops it;
+           - the target selectors' pass schedule as their code EXECUTES it (getXsUs_Cs
+             mpcUtil.py:302-310, getXsUs :224-233): xs/us are views of the solution buffer,
+             which the next solve overwrites before the "old" values are taken, so the stop
+             test passes from the second solve on - sample 0 takes at most two passes, every
+             later sample one, embedded at the previous sample's target.  With this schedule
+             the closed loop reproduces the reference's recorded Experiments/lpv_counter.npy
+             in 450 of 450 steps (446 with every sample iterated to convergence).
   intended - scheduling points (lam x_k, lam u_k) for A_k,B_k and lam x_{k+1} for C_k instead
              of the kron/reshape pairing of NMPC_test.py:167-173;
            - h = c - D y - M Z (Phi x0 + F0) - M H0 as a vector (NMPC_test.py:217 broadcasts
@@ -24,8 +31,15 @@ from .qp import solve_qp
 
 
 def target_selector(model, y_ref_norm, Nsim, u_min, u_max, y_min, y_max, nodes, weights,
-                    max_lpv=20, tol=1e-4, lam=1000.0):
-    """Steady-state targets (xs, us) per reference sample, warm-started along the sequence."""
+                    max_lpv=20, tol=1e-4, lam=1000.0, as_executed=False):
+    """Steady-state targets (xs, us) per reference sample, warm-started along the sequence.
+
+    as_executed=False iterates every sample until (xs, us) stop changing (<= max_lpv passes), the
+    evident intent of mpcUtil.py:288-313.  as_executed=True reproduces what that code DOES: xs and
+    us are views of the buffer `xue` (mpcUtil.py:306-307) that the next `xue[:] = solve_qp(...)`
+    (:302) overwrites BEFORE `xold = np.copy(xs)` (:304) is taken, so from the second solve on the
+    stop test compares the new solution with itself and passes: sample 0 takes at most two passes
+    and every later sample exactly one, embedded at the previous sample's target."""
     nx, nu, ny, ne = model.nx, model.nu, model.ny, 1
     assert nu == 1 and ny == 1
     Q = np.eye(ny); R = np.eye(nu)
@@ -55,6 +69,8 @@ def target_selector(model, y_ref_norm, Nsim, u_min, u_max, y_min, y_max, nodes, 
             xold, uold = xs, us
             xs, us, e = z[:nx], z[nx:nx + nu], z[nx + nu:]
             iters[j] = i + 1
+            if as_executed and (j > 0 or i > 0):
+                break
             if np.linalg.norm(xs - xold) <= tol and np.linalg.norm(us - uold) <= tol:
                 break
         Xs[:, j], Us[:, j], Es[:, j] = xs, us, e
@@ -86,12 +102,18 @@ def mpc_qp(list_A, list_B, list_C, x0, y_meas, Xs, Us, f0, h0, Psi, Omega, D, E,
 
 def output_nmpc_linear(model, u_min, u_max, y_min, y_max, x0, Q, R, dt, stages, y_reference_list,
                        Nc=5, Nsim=30, max_iterations=1, tol=1e-1, rho=1000.0, noise=None,
-                       rule="simpson", dlam=None, targets=None, plant_x0=None, merge=True):
+                       rule="simpson", dlam=None, targets=None, plant_x0=None, merge=True, target_as_executed=True,
+                       embed_fn=None, timers=None):
     """Closed loop of the output-constrained LPV-NMPC with observer, single controller.
 
     noise: optional array [Nsim] added to the measured angle (sigma_n of the plant).
+    embed_fn: alternative to lpv.embed with the same signature (lpv.embed_functorch).
+    timers: optional float array [Nsim, 4] that receives per-step seconds in the reference's buckets
+    (NMPC_test.py:152-300): getAB (embedding), solve (condensing + QP + prediction), overhead, sim (plant).
     Returns a dict of logs named as the reference's return tuple (NMPC_test.py:320).
     """
+    import time
+    embed = lpv.embed if embed_fn is None else embed_fn
     nx, nu, ny = model.nx, model.nu, model.ny
     nodes, weights = lpv.quad_nodes(rule, stages, dlam)
     if merge:
@@ -107,7 +129,7 @@ def output_nmpc_linear(model, u_min, u_max, y_min, y_max, x0, Q, R, dt, stages, 
     y_ref_n = np.clip(y_ref_n, ymin_n, ymax_n)
     if targets is None:
         Xs_all, Us_all, _, _ = target_selector(model, y_ref_n, Nsim + Nc, umin_n, umax_n, ymin_n, ymax_n,
-                                               nodes, weights)
+                                               nodes, weights, as_executed=target_as_executed)
     else:
         Xs_all, Us_all = targets
     f0 = np.asarray(model.f0).reshape(nx); h0 = np.asarray(model.h0).reshape(ny)
@@ -126,23 +148,29 @@ def output_nmpc_linear(model, u_min, u_max, y_min, y_max, x0, Q, R, dt, stages, 
     lpv_counter = np.zeros(Nsim, int)
     plan_log = np.zeros((Nsim, Nc)); abc_first = None
     for k in range(Nsim):
+        t_step = time.perf_counter(); t_ab = t_solve = 0.0
         Xs = Xs_all[:, k + 1:k + Nc + 1].T.reshape(nx * Nc)
         Us = Us_all[:, k:k + Nc].T.reshape(Nc * nu)
         while True:
+            t0 = time.perf_counter()
             xsched = np.concatenate([x0n, x[:-nx]]).reshape(Nc, nx)
-            A, B, C = lpv.embed(model, xsched, u.reshape(Nc, nu), nodes, weights, xc=x.reshape(Nc, nx))
+            A, B, C = embed(model, xsched, u.reshape(Nc, nu), nodes, weights, xc=x.reshape(Nc, nx))
             lA, lB, lC = A.reshape(Nc * nx, nx), B.reshape(Nc * nx, nu), C.reshape(Nc * ny, nx)
+            t1 = time.perf_counter()
             if abc_first is None:
                 abc_first = (lA.copy(), lB.copy(), lC.copy())
             u_old = u.copy()
             u, eps, x, _ = mpc_qp(lA, lB, lC, x0n, y_meas_n, Xs, Us, f0, h0, Psi, Omega, D, E, M, c,
                                   Nc, nx, nu, ny, rho)
+            t_ab += t1 - t0; t_solve += time.perf_counter() - t1
             lpv_counter[k] += 1
             if lpv_counter[k] >= max_iterations or np.linalg.norm(u - u_old) < tol:
                 break
         plan_log[k] = u
         u_den = model.ustd * u[0] + model.u0
+        t0 = time.perf_counter()
         xp = disc_step(xp, u_den, dt)
+        t_sim = time.perf_counter() - t0
         y_meas = xp[1] + (0.0 if noise is None else noise[k])
         y_meas_n = np.atleast_1d((y_meas - model.y0) / model.ystd)
         uhist = np.append(uhist[1:], u[0])
@@ -155,6 +183,9 @@ def output_nmpc_linear(model, u_min, u_max, y_min, y_max, x0, Q, R, dt, stages, 
         x = np.concatenate([x[nx:], x[-nx:]])
         x0n = zest.copy()
         u = np.concatenate([u[nu:], u[-nu:]])
+        if timers is not None:
+            tot = time.perf_counter() - t_step
+            timers[k] = (t_ab, t_solve, tot - t_ab - t_solve - t_sim, t_sim)
     return dict(x_log=x_log, u_log=u_log, e_log=e_log, lpv_counter=lpv_counter, y_log=y_log,
                 y_est_log=y_est_log, Xs=Xs_all, Us=Us_all, plan_log=plan_log, abc_first=abc_first,
                 y_ref_n=y_ref_n)
@@ -170,12 +201,13 @@ def output_nmpc_linear(model, u_min, u_max, y_min, y_max, x0, Q, R, dt, stages, 
 #   - input targets follow the step, Us = us[k : k+Nc]  (NMPC.py:580 always takes the first Nc);
 #   - linear cost term 2 (Gamma' Omega (Phi x0 - Xs) - Psi Us)  (NMPC.py:591 adds Psi' Us);
 #   - the input warm start shifts by nu  (NMPC.py:495,640 shift it by nx);
-#   - getXsUs iterates until xs, us stop changing (mpcUtil.py:226-233 compares xs with a view of the
-#     buffer the next solve overwrites, which ends the loop after one repeat).
 def target_selector_state(model, y_ref_norm, Nsim, u_min, u_max, x_min, x_max, C, nodes, weights,
-                          f0=None, h0=0.0, max_lpv=10, tol=1e-5, lam=100.0):
+                          f0=None, h0=0.0, max_lpv=10, tol=1e-5, lam=100.0, as_executed=True):
     """mpcUtil.py:167-239 getXsUs: steady states with box constraints on (xs, us), fixed output
-    matrix C; returns Xs [nx, Nsim], Us [nu, Nsim], Es [1, Nsim], iteration counts."""
+    matrix C; returns Xs [nx, Nsim], Us [nu, Nsim], Es [1, Nsim], iteration counts.
+    as_executed: the pass schedule of the code as it runs (mpcUtil.py:224-233 compares xs with a view
+    of the buffer the next solve overwrites: at most two passes for sample 0, one afterwards);
+    False iterates every sample until xs, us stop changing."""
     nx, nu, ne = model.nx, model.nu, 1
     C = np.atleast_2d(np.asarray(C, float)); ny = C.shape[0]
     Q = np.eye(ny); R = np.eye(nu)
@@ -203,6 +235,8 @@ def target_selector_state(model, y_ref_norm, Nsim, u_min, u_max, x_min, x_max, C
             xold, uold = xs, us
             xs, us, e = z[:nx].copy(), z[nx:nx + nu].copy(), z[nx + nu:].copy()
             iters[j] = i + 1
+            if as_executed and (j > 0 or i > 0):
+                break
             if np.linalg.norm(xs - xold) <= tol and np.linalg.norm(us - uold) <= tol:
                 break
         Xs[:, j], Us[:, j], Es[:, j] = xs, us, e

@@ -16,7 +16,10 @@ pytestmark = pytest.mark.gpu
 Q = np.diag([1000.0, 10.0])
 
 
-def test_target_selector_vs_oracle(enc, omodel):
+@pytest.mark.parametrize("max_lpv", [0, 20])
+def test_target_selector_vs_oracle(enc, omodel, max_lpv):
+    """max_lpv = 0: the pass schedule the reference's code executes (two passes at most for sample 0, one
+    afterwards); 20: every sample iterated until the target stops moving."""
     import nmpc_amd
     s = disc_setup(omodel)
     Nsamp, B = 70, 5
@@ -25,17 +28,24 @@ def test_target_selector_vs_oracle(enc, omodel):
     yrn = np.clip((refs - omodel.y0) / omodel.ystd, s["ymin"], s["ymax"])
     lam, w = nmpc_amd.quad_nodes("simpson", 20)
     Xs, Us, Es, it = nmpc_amd.getXsUs_Cs(yrn, 2, 1, 1, Nsamp, s["umin"], s["umax"], s["ymin"], s["ymax"],
-                                         nmpc_amd.GetABC(enc, lam, w), return_iters=True)
+                                         nmpc_amd.GetABC(enc, lam, w), return_iters=True, max_lpv=max_lpv)
     assert Xs.shape == (B, 2, Nsamp) and Us.shape == (B, 1, Nsamp)
     nodes, weights = olpv.merge_nodes(*olpv.quad_nodes("simpson", 20))
     for b in range(B):
-        xo, uo, eo, ito = target_selector(omodel, yrn[b], Nsamp, s["umin"], s["umax"], s["ymin"], s["ymax"], nodes, weights)
+        xo, uo, eo, ito = target_selector(omodel, yrn[b], Nsamp, s["umin"], s["umax"], s["ymin"], s["ymax"], nodes, weights,
+                                          as_executed=max_lpv == 0)
         assert np.abs(Xs[b].cpu().numpy() - xo).max() < 1e-5
         assert np.abs(Us[b].cpu().numpy() - uo).max() < 1e-5
         assert np.abs(Es[b].cpu().numpy() - eo).max() < 1e-5
-        assert (it[b].cpu().numpy() == ito).mean() > 0.97      # the 1e-4 stop test may flip on rounding
+        same = (it[b].cpu().numpy() == ito).mean()
+        print("target selector max_lpv=%d controller %d: pass counts equal in %.4f of the samples" % (max_lpv, b, same))
+        # as executed the schedule is fixed (2, 1, 1, ...); iterated, the 1e-4 stop test may flip on rounding
+        assert same == 1.0 if max_lpv == 0 else same >= 0.97
+    if max_lpv == 0:
+        assert int(it[:, 0].max()) <= 2 and int(it[:, 1:].max()) == 1
     # un-batched call, as the reference makes it
-    x1, u1, e1 = nmpc_amd.getXsUs_Cs(yrn[0], 2, 1, 1, Nsamp, s["umin"], s["umax"], s["ymin"], s["ymax"], nmpc_amd.GetABC(enc, lam, w))
+    x1, u1, e1 = nmpc_amd.getXsUs_Cs(yrn[0], 2, 1, 1, Nsamp, s["umin"], s["umax"], s["ymin"], s["ymax"], nmpc_amd.GetABC(enc, lam, w),
+                                     max_lpv=max_lpv)
     assert x1.shape == (2, Nsamp) and torch.equal(x1, Xs[0])
 
 
@@ -224,8 +234,8 @@ def test_recorded_closed_loop_of_the_reference(enc):
     # configuration); the pass count follows from the step's QP solutions through the stop test
     rec = np.load(os.path.join(GOLDEN, "ref_lpv_counter.npy"))
     c = out[6].cpu().numpy().reshape(-1)
-    assert (c == rec).mean() >= 0.98 and abs(int(c.sum()) - int(rec.sum())) <= 3
-    assert np.array_equal(c[:60], rec[:60])
+    print("recorded lpv_counter: %d of 450 steps equal, totals %d / %d" % (int((c == rec).sum()), int(c.sum()), int(rec.sum())))
+    assert np.array_equal(c, rec)          # every one of the 450 steps takes the recorded number of passes
 
 
 def test_noisy_converged_configuration_at_scale(enc, omodel):

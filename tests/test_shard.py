@@ -34,6 +34,11 @@ WORKER = textwrap.dedent("""
     out = gather_logs({k: v[lo:hi].clone() for k, v in full.items()}, total=total)
     for k in full:
         assert torch.equal(out[k], full[k]), k
+    # gather to one rank, shard lengths known to the caller (no size exchange)
+    sizes = [b - a for a, b in (shard_range(total, r, world) for r in range(world))]
+    out = gather_logs({k: v[lo:hi].clone() for k, v in full.items()}, dst=1, sizes=sizes)
+    for k in full:
+        assert torch.equal(out[k], full[k] if rank == 1 else full[k][lo:hi]), k
     s = reduce_stats([float(hi - lo), 1.0], "sum")
     assert s == [float(total), float(world)], s
     m = reduce_stats([float(rank)], "max")
