@@ -191,6 +191,19 @@ int nmpc_target_select_ws(const nmpc_model* m, int nb, int nsamp, const double* 
                           int n_nodes, int max_lpv, double tol, double* Xs, double* Us, double* Es,
                           int* iters, int* status, void* workspace, unsigned long long workspace_bytes,
                           void* stream);
+/* No counterpart in the reference: nmpc_target_select for callers that cannot allocate device memory (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  Same arguments and results as
+ * nmpc_target_select; the workspace is a static device array of NMPC_TARGET_STATIC_BYTES inside the library
+ * (one copy per GPU, held until the process ends), so the call allocates nothing, frees nothing and does not
+ * synchronise: everything is issued asynchronously on `stream`.  Sizes whose workspace
+ * (nmpc_target_workspace_bytes) exceeds NMPC_TARGET_STATIC_BYTES are rejected with an error - about 55 000
+ * controllers at nx = 2, 9 600 at nx = 8.  All calls on one GPU share the array: calls that overlap in time on
+ * the same GPU (different streams or threads) race; serialise them or use nmpc_target_select_ws. */
+#define NMPC_TARGET_STATIC_BYTES (4u << 20)
+int nmpc_target_select_static(const nmpc_model* m, int nb, int nsamp, const double* y_ref_n, double u_min,
+                              double u_max, double y_min, double y_max, const float* lam, const float* w,
+                              int n_nodes, int max_lpv, double tol, double* Xs, double* Us, double* Es,
+                              int* iters, int* status, void* stream);
 /* State-constrained selector (reference: mpcUtil.py:167-239 getXsUs, called at NMPC.py:541-542): the
  * same iteration with A, B only, a fixed output row C[nx] (host), equality offsets f0[nx] (host; NULL =
  * the model's f(0,0)) and h0, and the soft box -u, u, -xs, xs (x_min[nx], x_max[nx], host, normalised).

@@ -40,6 +40,8 @@ SIGNATURES = {
     "nmpc_ctrl_run": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int] + [c_void_p] * 11),
     "nmpc_target_select": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, c_void_p] + [ctypes.c_double] * 4 +
                            [c_float_p, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_double] + [c_void_p] * 6),
+    "nmpc_target_select_static": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, c_void_p] + [ctypes.c_double] * 4 +
+                                  [c_float_p, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_double] + [c_void_p] * 6),
     "nmpc_target_select_state": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, c_void_p, ctypes.c_double,
                                                 ctypes.c_double, c_double_p, c_double_p, c_double_p, c_double_p,
                                                 ctypes.c_double, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int,

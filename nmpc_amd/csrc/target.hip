@@ -10,6 +10,7 @@
 // nx+1 unknowns (xs, us), so they fix (xs, us) and the QP only chooses the slack:
 // e = max(0, largest row violation).  That closed form is what the kernel evaluates (Gaussian
 // elimination with partial pivoting, fp64); a singular system is flagged in `status`.
+#include <atomic>
 #include <vector>
 
 #include "../../include/nmpc_amd.h"
@@ -232,6 +233,47 @@ static int target_check_ws(const nmpc_model* m, const TargetArgs& a, const void*
     const size_t need = target_ws_bytes(m->d.nx, a.nb, a.max_lpv);
     NMPC_REQUIRE(ws_bytes >= need, "nmpc_target_select: workspace of %llu bytes is too small (%zu needed)", ws_bytes, need);
     return 0;
+}
+
+// ---- allocation-free form -----------------------------------------------------------------------
+// Scratch of nmpc_target_select_static: part of the code object, so every GPU the library runs on holds
+// its own copy at its own address until the process ends.  In host code the array's NAME is only a
+// stand-in for the symbol; the device address is looked up once per device and kept in scratch_ptr.
+constexpr size_t TARGET_STATIC_BYTES = (size_t)NMPC_TARGET_STATIC_BYTES;
+static __device__ __align__(256) unsigned char scratch[TARGET_STATIC_BYTES];
+constexpr int TARGET_MAX_DEVICES = 64;
+static std::atomic<void*> scratch_ptr[TARGET_MAX_DEVICES];
+
+// device address of `scratch` on the current device (looked up on the first call on that device)
+static int target_static_scratch(char** out) {
+    int dev = -1;
+    NMPC_HIP_CHECK(hipGetDevice(&dev));
+    NMPC_REQUIRE(dev >= 0 && dev < TARGET_MAX_DEVICES, "nmpc_target_select_static: device %d out of range", dev);
+    void* p = scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!p) {
+        NMPC_HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        NMPC_REQUIRE(p != nullptr, "nmpc_target_select_static: no device address for the scratch array");
+        scratch_ptr[dev].store(p, std::memory_order_release);     // racing threads store the same address
+    }
+    *out = (char*)p;
+    return 0;
+}
+
+extern "C" int nmpc_target_select_static(const nmpc_model* m, int nb, int nsamp, const double* y_ref_n, double u_min,
+                                         double u_max, double y_min, double y_max, const float* lam, const float* w,
+                                         int n_nodes, int max_lpv, double tol, double* Xs, double* Us, double* Es,
+                                         int* iters, int* status, void* stream) {
+    TargetArgs a;
+    if (target_fill_output(m, a, nb, nsamp, y_ref_n, u_min, u_max, y_min, y_max, lam, w, n_nodes, max_lpv, tol, Xs, Us, Es,
+                           iters, status)) return 1;
+    const size_t need = target_ws_bytes(m->d.nx, nb, max_lpv);
+    NMPC_REQUIRE(need <= TARGET_STATIC_BYTES,
+                 "nmpc_target_select_static: %d controllers with nx=%d need %zu bytes of scratch, the static buffer holds %zu "
+                 "(use nmpc_target_select_ws with a caller workspace)", nb, m->d.nx, need, TARGET_STATIC_BYTES);
+    char* ws = nullptr;
+    if (target_static_scratch(&ws)) return 1;
+    // target_issue clears the part of the scratch it uses (it still holds the previous call's contents)
+    return target_issue(m, a, lam, w, n_nodes, ws, stream);
 }
 
 extern "C" unsigned long long nmpc_target_workspace_bytes(int nx, int nb, int max_lpv) {
