@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "mpc_kernels.h"
+#include "mpc_wide.h"
 
 namespace nmpc {
 
@@ -249,6 +250,7 @@ static int mpc_geom(int Nc, int nx, int mode, int slack, MpcGeom& g) {
 using namespace nmpc;
 
 static int dispatch_mpc_qp(const MpcQpArgs& a, const MpcGeom& g, hipStream_t s) {
+    if (mpc_wide_applies(a.c.Nc, a.nx, a.c.mode, a.c.slack)) return launch_mpc_qp_wide(a, s);
     if (a.nx == 2) return dispatch_mpc_qp_nx2(a, g, s);
     if (a.nx == 3) return dispatch_mpc_qp_nx3(a, g, s);
     if (a.nx == 4) return dispatch_mpc_qp_nx4(a, g, s);
@@ -257,6 +259,7 @@ static int dispatch_mpc_qp(const MpcQpArgs& a, const MpcGeom& g, hipStream_t s) 
 }
 
 static int dispatch_mpc_solve(const CtrlDev& d, const RunPtrs& rp, int it, int k, const MpcGeom& g, hipStream_t s) {
+    if (mpc_wide_applies(d.Nc, d.nx, d.c.mode, d.c.slack)) return launch_mpc_solve_wide(d, rp, it, k, s);
     if (d.nx == 2) return dispatch_mpc_solve_nx2(d, rp, it, k, g, s);
     if (d.nx == 3) return dispatch_mpc_solve_nx3(d, rp, it, k, g, s);
     if (d.nx == 4) return dispatch_mpc_solve_nx4(d, rp, it, k, g, s);

@@ -1,0 +1,558 @@
+// Condensing + QP for LONG horizons (reference: NMPC_test.py:206-238 with Nc of 16..63; the reference's
+// long-horizon runs use Nc = 50): one WORKGROUP of four wavefronts per controller instead of one wavefront.
+//
+// A QP with n = Nc + 1 variables and 4 Nc + 2 rows keeps a single wavefront busy for about a million cycles
+// (every phase is bound by that one wave's instruction issue), so here the row-parallel phases run on all
+// 256 lanes and the storage is cut to what the structure of the problem needs:
+//   * the rows come in pairs  -a'u - eps <= h-,  +a'u - eps <= h+  (input bounds: a = e_i; output bounds:
+//     a = (C_i Gamma_{i,:})'), and the Hessian is blkdiag(G, rho), so in the solver's coordinates
+//     zt = L'z both rows of a pair have the normals [+-alpha; 1/sqrt(rho)] with ONE vector
+//     alpha = L_G^-1 a: the pair table Al[k][pair] holds alpha, half the rows of the dense formulation,
+//     and the slack variable never enters a product;
+//   * lane 2 p + h owns row h of pair p: its slack lives in a register, every Nc-long dot product of a pair
+//     is split between the pair's two lanes and combined with one DPP swap;
+//   * the small sequential parts of the dual active-set iteration (triangular solves with the working
+//     set's factor, step lengths, the decision which row enters or leaves) are computed by every wave
+//     redundantly from the same LDS data, bit for bit the same, which leaves two workgroup barriers per
+//     iteration (candidate search, Gram column of the candidate);
+//   * the Cholesky factorisation of G runs in one wave with one matrix row per lane in registers (pivot
+//     column through v_readlane) while the other waves build the right-hand sides.
+// The algorithm is the Goldfarb-Idnani iteration of qp_gi.h (same pivoting rule, tolerances and status
+// codes); only the data layout and the work distribution differ.
+#pragma once
+#include "mpc_kernels.h"
+
+namespace nmpc {
+
+constexpr int WIDE_THREADS = 256;
+
+__host__ __device__ inline int wide_npairs(int Nc) { return 2 * Nc + 1; }
+// Columns of the pair table: the pairs, then the linear term; padded to 16 mod 32 so that the two lanes of a
+// pair, which read rows k and k+1 of the table in the same instruction, fall into different halves of the banks.
+__host__ __device__ inline int wide_cols(int Nc) { return ((wide_npairs(Nc) + 1 + 15) / 32) * 32 + 16; }
+
+struct WideLds {
+    double *Lm, *Lw, *Al, *Gam, *Ak, *Bk, *Ck, *qd, *xi, *x0, *Xs, *Us, *uold, *hv, *invdL, *invdW, *Dp, *usol, *avec, *red;
+    int* Wtab;
+    __host__ __device__ static int doubles(int Nc, int nx) {
+        const int n = Nc + 1, NPc = wide_cols(Nc);
+        return Nc * Nc + n * n + Nc * NPc + Nc * (Nc + 1) / 2 * nx + Nc * nx * nx + 5 * Nc * nx + 4 + 2 * Nc + 2 * wide_npairs(Nc) + 2 +
+               Nc + n + NPc + n + 4 * 64 + 32 + 2 * n + 2;
+    }
+    __device__ void carve(double* p, int Nc, int nx) {
+        const int n = Nc + 1, NPc = wide_cols(Nc);
+        Lm = p; p += Nc * Nc; Lw = p; p += n * n; Al = p; p += Nc * NPc; Gam = p; p += Nc * (Nc + 1) / 2 * nx;
+        Ak = p; p += Nc * nx * nx; Bk = p; p += Nc * nx; Ck = p; p += Nc * nx; qd = p; p += Nc * nx; xi = p; p += Nc * nx;
+        Xs = p; p += Nc * nx; x0 = p; p += 4; Us = p; p += Nc; uold = p; p += Nc; hv = p; p += 2 * wide_npairs(Nc) + 2;
+        invdL = p; p += Nc; invdW = p; p += n; Dp = p; p += NPc; usol = p; p += n; avec = p; p += 4 * 64; red = p; p += 32;
+        Wtab = reinterpret_cast<int*>(p);     // n pair ids, then n signs as doubles behind them
+    }
+};
+
+// red: [0..3] score, [4..7] slack of the candidate, [8..11] row (as double), [12] sp after a drop, [13] flag
+__device__ __forceinline__ double dpp_swap1(double v) { return dpp_d<DPP_XOR1>(v); }
+
+// Cholesky of the leading n x n block of Lm (row-major, ld n, lower triangle valid), one wave, row i in the
+// registers of lane i.  Rows take the update over their whole tail: entries right of the diagonal are never read.
+template <int NMAX>
+__device__ __attribute__((noinline)) bool wide_chol_regs(double* Lm, double* invd, int n) {
+    const int lane = threadIdx.x & 63;
+    double row[NMAX];
+#pragma unroll
+    for (int c = 0; c < NMAX; ++c) row[c] = (lane < n && c <= lane) ? Lm[lane * n + c] : 0.0;
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j) {
+        if (j < n) {
+            const double d = readlane_d(row[j], j);
+            if (!(d > 0.0)) ok = false;
+            const double inv = rsqrt_d(d > 0.0 ? d : 1.0);
+            row[j] *= inv;
+            if (lane == 0) invd[j] = inv;
+#pragma unroll
+            for (int c = j + 1; c < NMAX; ++c)
+                if (c < n) row[c] = fma(-row[j], readlane_d(row[j], c), row[c]);
+        }
+    }
+    if (lane < n) {
+#pragma unroll
+        for (int c = 0; c < NMAX; ++c)
+            if (c <= lane) Lm[lane * n + c] = row[c];
+    }
+    return ok;
+}
+
+struct WideDump { double *Ge, *Fe, *Le, *hv; };
+
+// On entry Ak, Bk, Ck, x0, Xs, Us are loaded (and a barrier passed).  On exit usol[0..Nc) = u, usol[Nc] = eps,
+// xi = predicted states; returns the solver status (uniform), *iters_out the active-set iterations.
+template <int NX>
+__device__ __forceinline__ int wide_solve(const MpcConst& c, WideLds& L, double ymeas, int* iters_out, const WideDump* dump,
+                                          unsigned long long* st = nullptr) {
+    // st (diagnostics): 12 clock stamps: [0] entry, after [1] recurrences [2] qd [3] Hessian / rows [4] Cholesky
+    // [5] transform [6] slack init [7] active-set loop [8] recovery of z [9] prediction
+    const int tid = threadIdx.x, lane = tid & 63;
+#define WIDE_STAMP(i) do { if (st && tid == 0) st[i] = __builtin_amdgcn_s_memtime(); } while (0)
+    WIDE_STAMP(0);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Nc = c.Nc, n = Nc + 1, NP = wide_npairs(Nc), NPc = wide_cols(Nc);
+    double* Al = L.Al;
+    // ---- P1: wave 0 runs the condensing recurrences (lane j < Nc: column j of Gamma; lane Nc: free response),
+    //          the other waves clear the pair table
+    if (wave == 0) {
+        const int j = lane;
+        const bool col = j < Nc, fr = j == Nc;
+        double v[NX], pf[NX], sf[NX];
+#pragma unroll
+        for (int r = 0; r < NX; ++r) { v[r] = col ? L.Bk[j * NX + r] : 0.0; pf[r] = c.f0[r]; sf[r] = c.f0[r]; }
+        if (fr) {
+#pragma unroll
+            for (int r = 0; r < NX; ++r) {
+                double a = 0.0;
+#pragma unroll
+                for (int l = 0; l < NX; ++l) a = fma(L.Ak[r * NX + l], L.x0[l], a);
+                v[r] = a;
+            }
+        }
+        auto emit = [&](int d) {
+            if (col && j + d < Nc) {
+#pragma unroll
+                for (int r = 0; r < NX; ++r) L.Gam[MpcLds::tri(j + d, j) * NX + r] = v[r];
+            }
+            if (fr) {
+#pragma unroll
+                for (int r = 0; r < NX; ++r) L.xi[d * NX + r] = v[r] + sf[r];
+            }
+        };
+        emit(0);
+        double An[NX * NX];
+#pragma unroll
+        for (int e = 0; e < NX * NX; ++e) An[e] = Nc > 1 ? L.Ak[NX * NX + e] : 0.0;
+        for (int d = 1; d < Nc; ++d) {
+            double A[NX * NX];
+#pragma unroll
+            for (int e = 0; e < NX * NX; ++e) A[e] = An[e];
+            const int dn = d + 1 < Nc ? d + 1 : d;           // next step's matrix is in flight during this one
+#pragma unroll
+            for (int e = 0; e < NX * NX; ++e) An[e] = L.Ak[dn * NX * NX + e];
+            double nv[NX], np[NX];
+#pragma unroll
+            for (int r = 0; r < NX; ++r) {
+                double a = 0.0, b2 = 0.0;
+#pragma unroll
+                for (int l = 0; l < NX; ++l) { a = fma(A[r * NX + l], v[l], a); b2 = fma(A[r * NX + l], pf[l], b2); }
+                nv[r] = a; np[r] = b2;
+            }
+#pragma unroll
+            for (int r = 0; r < NX; ++r) { v[r] = nv[r]; pf[r] = np[r]; sf[r] += np[r]; }
+            emit(d);
+        }
+    } else {
+        for (int e = tid - 64; e < Nc * NPc; e += WIDE_THREADS - 64) Al[e] = 0.0;
+    }
+    __syncthreads();
+    WIDE_STAMP(1);
+    // ---- P2: qd_i = Q (xi_i - Xs_i)
+    for (int e = tid; e < Nc * NX; e += WIDE_THREADS) {
+        const int i = e / NX, r = e % NX;
+        double a = 0.0;
+#pragma unroll
+        for (int l = 0; l < NX; ++l) a = fma(c.Q[r * NX + l], L.xi[i * NX + l] - L.Xs[i * NX + l], a);
+        L.qd[e] = a;
+    }
+    if (tid < Nc) Al[tid * NPc + 2 * tid] = 1.0;             // pair 2 i: the bounds on u_i, a = e_i
+    __syncthreads();
+    WIDE_STAMP(2);
+    // ---- P3: Hessian (lower triangle), linear term, output-row coefficients: one item per pair (a, b <= a)
+    const int items = Nc * (Nc + 1) / 2;
+    for (int t = tid; t < items; t += WIDE_THREADS) {
+        int a_ = (int)((__builtin_sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        while ((a_ + 1) * (a_ + 2) / 2 <= t) ++a_;
+        while (a_ * (a_ + 1) / 2 > t) --a_;
+        const int b_ = t - a_ * (a_ + 1) / 2;
+        double g = 0.0, f = 0.0;
+        int ta = MpcLds::tri(a_, a_), tb = MpcLds::tri(a_, b_);
+        for (int i = a_; i < Nc; ++i) {
+            double ga[NX], gb[NX];
+#pragma unroll
+            for (int r = 0; r < NX; ++r) { ga[r] = L.Gam[ta * NX + r]; gb[r] = L.Gam[tb * NX + r]; }
+#pragma unroll
+            for (int r = 0; r < NX; ++r) {
+                double qg = 0.0;
+#pragma unroll
+                for (int l = 0; l < NX; ++l) qg = fma(c.Q[r * NX + l], gb[l], qg);
+                g = fma(ga[r], qg, g);
+                f = fma(ga[r], L.qd[i * NX + r], f);
+            }
+            ta += i + 1; tb += i + 1;
+        }
+        L.Lm[a_ * Nc + b_] = 2.0 * (g + (a_ == b_ ? c.R : 0.0));
+        if (a_ == b_) Al[a_ * NPc + NP] = 2.0 * (f - c.R * L.Us[a_]);
+        double cg = 0.0;
+#pragma unroll
+        for (int r = 0; r < NX; ++r) cg = fma(L.Ck[a_ * NX + r], L.Gam[MpcLds::tri(a_, b_) * NX + r], cg);
+        const int pair = a_ + 1 < Nc ? 2 * (a_ + 1) + 1 : 2 * Nc;      // y_{a+1}: rows -/+ of block a+1; y_Nc last
+        Al[b_ * NPc + pair] = cg;
+    }
+    __syncthreads();
+    WIDE_STAMP(3);
+    // ---- P4: right-hand sides; P5: Cholesky of G in wave 0 beside it (after the optional dumps)
+    auto fill_hv = [&](int first, int stride) {
+        for (int row = first; row < 2 * NP; row += stride) {
+            const int p = row >> 1, h = row & 1;
+            double hval;
+            if (!(p & 1) && p < 2 * Nc) {
+                hval = h ? c.umax : -c.umin;
+            } else {
+                const int blk = p == 2 * Nc ? Nc : (p - 1) >> 1;
+                double yv = ymeas;
+                if (blk > 0) {
+                    yv = c.h0;
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) yv = fma(L.Ck[(blk - 1) * NX + r], L.xi[(blk - 1) * NX + r], yv);
+                }
+                hval = h ? c.ymax - yv : yv - c.ymin;
+            }
+            L.hv[row] = hval;
+        }
+    };
+    bool chol_ok = true;
+    if (dump) {
+        fill_hv(tid, WIDE_THREADS);
+        __syncthreads();
+        const int mt = 2 * NP;
+        if (dump->Ge) for (int e = tid; e < n * n; e += WIDE_THREADS) {
+            const int i = e / n, j = e % n;
+            dump->Ge[e] = (i < Nc && j < Nc) ? (j <= i ? L.Lm[i * Nc + j] : 0.0) : (i == Nc && j == Nc ? c.rho : 0.0);
+        }
+        if (dump->Fe) for (int e = tid; e < n; e += WIDE_THREADS) dump->Fe[e] = e < Nc ? Al[e * NPc + NP] : 0.0;
+        if (dump->Le) for (int e = tid; e < mt * n; e += WIDE_THREADS) {
+            const int row = e / n, k = e % n;
+            dump->Le[e] = k == Nc ? -1.0 : ((row & 1) ? 1.0 : -1.0) * Al[k * NPc + (row >> 1)];
+        }
+        if (dump->hv) for (int e = tid; e < mt; e += WIDE_THREADS) dump->hv[e] = L.hv[e];
+        __syncthreads();
+        if (wave == 0) chol_ok = Nc <= 32 ? wide_chol_regs<32>(L.Lm, L.invdL, Nc) : wide_chol_regs<64>(L.Lm, L.invdL, Nc);
+    } else if (wave == 0) {
+        chol_ok = Nc <= 32 ? wide_chol_regs<32>(L.Lm, L.invdL, Nc) : wide_chol_regs<64>(L.Lm, L.invdL, Nc);
+    } else {
+        fill_hv(tid - 64, WIDE_THREADS - 64);
+    }
+    if (tid == 0) L.red[13] = chol_ok ? 1.0 : 0.0;
+    __syncthreads();
+    if (L.red[13] == 0.0) {
+        if (iters_out) *iters_out = 0;
+        return 3;
+    }
+    WIDE_STAMP(4);
+    // ---- P6: alpha = L_G^-1 a for every pair, and zt = -L_G^-1 F (column NP).  Lane 2 i + h works on
+    //          column i; the dot over l < k is split by the parity of l between the two lanes.
+    const int ci = tid >> 1, h = tid & 1;
+    const bool has_col = ci <= NP;
+    const int cc = has_col ? ci : NP;
+    {
+        const double sgn = ci == NP ? -1.0 : 1.0;            // the linear term q enters as right-hand side -q
+        double yprev = 0.0;
+        for (int k = 0; k < Nc; ++k) {
+            double part = 0.0;
+            const double* Lk = L.Lm + k * Nc;
+#pragma unroll 4
+            for (int l = h; l < k - 1; l += 2) part = fma(Lk[l], Al[l * NPc + cc], part);
+            part += dpp_swap1(part);
+            double v = sgn * Al[k * NPc + cc] - part;
+            if (k > 0) v = fma(-Lk[k - 1], yprev, v);
+            const double y = v * L.invdL[k];
+            // lane h = 0 stores; the entry is read back two rows later at the earliest (same wave: in order)
+            if (has_col && h == 0) Al[k * NPc + cc] = y;
+            yprev = y;
+        }
+    }
+    __syncthreads();
+    WIDE_STAMP(5);
+    // ---- P7: slacks s = h + nt . zt_unc (the slack component of zt_unc is zero).  Lane 2 p + h owns row h of pair p.
+    const int row = tid, pi = tid >> 1;
+    const bool has_row = pi < NP;
+    const int pc = has_row ? pi : NP - 1;
+    const double sigma = 1.0 / sqrt(c.rho), sig2 = 1.0 / c.rho;
+    double s = 0.0, iscale = 1.0;
+    {
+        double part = 0.0;
+#pragma unroll 4
+        for (int k = h; k < Nc; k += 2) part = fma(Al[k * NPc + pc], Al[k * NPc + NP], part);
+        part += dpp_swap1(part);
+        if (has_row) {
+            const double hval = L.hv[row];
+            iscale = 1.0 / (1.0 + fabs(hval));
+            s = hval + (h ? -part : part);
+        }
+    }
+    WIDE_STAMP(6);
+    // ---- P8: dual active-set iteration
+    int q = 0, iters = 0, status = 0;
+    double lamj = 0.0, wsgj = 1.0;      // lane j < q of EVERY wave: multiplier, pair and sign of working-set member j
+    int wpj = 0;
+    bool inW = false;
+    const int max_iter = 10 * (n + 2 * NP) + 20;
+    double* avec = L.avec + wave * 64;
+    for (;;) {
+        double best = QP_INF; int bi = 0x7fffffff;
+        if (has_row && !inW) { best = s * iscale; bi = row; }
+        g_argmin<64>(best, bi);
+        if (has_row && row == bi) L.red[4 + wave] = s;
+        if (lane == 0) { L.red[wave] = best; L.red[8 + wave] = (double)bi; }
+        __syncthreads();
+        double gb = L.red[0], sp = L.red[4]; int p = (int)L.red[8];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const double v = L.red[w]; const int vi = (int)L.red[8 + w];
+            if (v < gb || (v == gb && vi < p)) { gb = v; p = vi; sp = L.red[4 + w]; }
+        }
+        if (!(gb < -1e-10)) break;
+        const int pp = p >> 1;
+        const double sgp = (p & 1) ? -1.0 : 1.0;
+        {   // Gram column of the candidate: Dp[i] = alpha_i . alpha_p
+            double part = 0.0;
+#pragma unroll 4
+            for (int k = h; k < Nc; k += 2) part = fma(Al[k * NPc + pc], Al[k * NPc + pp], part);
+            part += dpp_swap1(part);
+            if (has_row && h == 0) L.Dp[pi] = part;
+        }
+        __syncthreads();
+        const double kpp = L.Dp[pp] + sig2;
+        double lam_p = 0.0;
+        for (;;) {
+            if (++iters > max_iter) { status = 1; break; }
+            const int glq = lane < q ? lane : 0;
+            double kp = lane < q ? fma(wsgj * sgp, L.Dp[wpj], sig2) : 0.0;
+            // l = Lw^-1 kp
+            double v = kp, lj = 0.0;
+            const double invw = L.invdW[glq];
+            {
+                double lnext = L.Lw[glq * n];
+                for (int i = 0; i < q; ++i) {
+                    const double lcur = lnext;
+                    if (i + 1 < q) lnext = L.Lw[glq * n + i + 1];
+                    const double li = readlane_d(v, i) * readlane_d(invw, i);
+                    if (lane == i) lj = li;
+                    if (lane > i && lane < q) v = fma(-lcur, li, v);
+                }
+            }
+            const double dd = kpp - wave_sum(lane < q ? lj * lj : 0.0);
+            // r = Lw^-T l
+            v = lj;
+            double rj = 0.0;
+            {
+                double lnext = q > 0 ? L.Lw[(q - 1) * n + glq] : 0.0;
+                for (int i = q - 1; i >= 0; --i) {
+                    const double lcur = lnext;
+                    if (i > 0) lnext = L.Lw[(i - 1) * n + glq];
+                    const double ri = readlane_d(v, i) * readlane_d(invw, i);
+                    if (lane == i) rj = ri;
+                    if (lane < i) v = fma(-lcur, ri, v);
+                }
+            }
+            double t1 = QP_INF; int kd = 0x7fffffff;
+            if (lane < q && rj > 1e-13) { t1 = lamj / rj; kd = lane; }
+            g_argmin<64>(t1, kd);
+            const bool primal = dd > 1e-12 * kpp && kpp > 0.0;
+            const double t2 = primal ? -sp / dd : QP_INF;
+            const double t = t1 < t2 ? t1 : t2;
+            if (!(t < QP_INF)) { status = 2; break; }
+            if (primal) {
+                // direction in zt coordinates, components k < Nc on lane k (every wave its own copy); the slack
+                // component is sigma (1 - sum r)
+                const int kr = lane < Nc ? lane : Nc - 1;
+                double a = sgp * Al[kr * NPc + pp];
+                const double rs = rj * wsgj;
+                for (int j = 0; j < q; ++j) a = fma(-Al[kr * NPc + __builtin_amdgcn_readlane(wpj, j)], readlane_d(rs, j), a);
+                const double vn = sigma * (1.0 - wave_sum(lane < q ? rj : 0.0));
+                g_sync();
+                avec[lane] = lane < Nc ? a : 0.0;
+                g_sync();
+                double part = 0.0;
+#pragma unroll 4
+                for (int k = h; k < Nc; k += 2) part = fma(Al[k * NPc + pc], avec[k], part);
+                part += dpp_swap1(part);
+                if (has_row) s = fma(t, (h ? -part : part) + sigma * vn, s);
+            }
+            if (lane < q) lamj -= t * rj;
+            lam_p += t;
+            if (primal && t2 <= t1) {          // full step: p joins the working set at position q
+                g_sync();
+                if (lane < q) L.Lw[q * n + lane] = lj;
+                if (lane == q) {
+                    const double dl = sqrt(dd);
+                    L.Lw[q * n + q] = dl; L.invdW[q] = 1.0 / dl;
+                    lamj = lam_p; wpj = pp; wsgj = sgp;
+                }
+                g_sync();
+                if (has_row && row == p) { s = 0.0; inW = true; }
+                ++q;
+                break;
+            }
+            // partial (or dual-only) step: the member at position kd leaves the working set
+            {
+                const int dropped = 2 * __builtin_amdgcn_readlane(wpj, kd) + (readlane_d(wsgj, kd) < 0.0 ? 1 : 0);
+                if (has_row && row == dropped) inW = false;
+                const double lnext = g_next<64>(lamj), snext = g_next<64>(wsgj);
+                const int wnext = g_next_i<64>(wpj);
+                if (lane >= kd && lane < q - 1) { lamj = lnext; wpj = wnext; wsgj = snext; }
+                --q;
+                if (lane >= q) { lamj = 0.0; wpj = 0; wsgj = 1.0; }
+                // rebuild Lw = chol(K_WW), K_ab = sg_a sg_b alpha_a . alpha_b + 1/rho, by the whole workgroup
+                double* Wsg = reinterpret_cast<double*>(L.Wtab + 2 * ((n + 1) / 2));
+                if (has_row && row == p) L.red[12] = s;
+                __syncthreads();               // every wave is done with the old factor
+                if (wave == 0 && lane < q) { L.Wtab[lane] = wpj; Wsg[lane] = wsgj; }
+                __syncthreads();
+                for (int e = tid; e < q * (q + 1) / 2; e += WIDE_THREADS) {
+                    int a_ = (int)((__builtin_sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+                    while ((a_ + 1) * (a_ + 2) / 2 <= e) ++a_;
+                    while (a_ * (a_ + 1) / 2 > e) --a_;
+                    const int b_ = e - a_ * (a_ + 1) / 2;
+                    const int wa = L.Wtab[a_], wb = L.Wtab[b_];
+                    double acc = 0.0;
+#pragma unroll 4
+                    for (int k = 0; k < Nc; ++k) acc = fma(Al[k * NPc + wa], Al[k * NPc + wb], acc);
+                    L.Lw[a_ * n + b_] = fma(Wsg[a_] * Wsg[b_], acc, sig2);
+                }
+                __syncthreads();
+                if (wave == 0) {
+                    const bool ok = chol_rows_lds(L.Lw, q, n, L.invdW);
+                    if (lane == 0) L.red[13] = ok ? 1.0 : 0.0;
+                }
+                __syncthreads();
+                if (L.red[13] == 0.0) { status = 2; break; }
+                sp = L.red[12];
+            }
+        }
+        if (status) break;
+    }
+    // ---- P9: z from the multipliers: L' z = zt_unc + Nt_W lam; wave 0 solves, the slack variable is separate
+    __syncthreads();
+    WIDE_STAMP(7);
+    if (wave == 0) {
+        const int kr = lane < Nc ? lane : Nc - 1;
+        double v = Al[kr * NPc + NP];
+        const double ls = lamj * wsgj;
+        for (int j = 0; j < q; ++j) v = fma(Al[kr * NPc + __builtin_amdgcn_readlane(wpj, j)], readlane_d(ls, j), v);
+        const double lsum = wave_sum(lane < q ? lamj : 0.0);
+        const double invl = L.invdL[kr];
+        double xres = 0.0, lnext = L.Lm[(Nc - 1) * Nc + kr];
+        for (int i = Nc - 1; i >= 0; --i) {
+            const double lcur = lnext;
+            if (i > 0) lnext = L.Lm[(i - 1) * Nc + kr];
+            const double xv = readlane_d(v, i) * readlane_d(invl, i);
+            if (lane == i) xres = xv;
+            if (lane < i) v = fma(-lcur, xv, v);
+        }
+        if (lane < Nc) L.usol[lane] = xres;
+        if (lane == 0) L.usol[Nc] = sig2 * lsum;
+    }
+    __syncthreads();
+    WIDE_STAMP(8);
+    // ---- P10: x_pred = Phi x0 + Gamma u + F0 (into xi)
+    for (int e = tid; e < Nc * NX; e += WIDE_THREADS) {
+        const int i = e / NX, r = e % NX;
+        double a = L.xi[e];
+        for (int j = 0; j <= i; ++j) a = fma(L.Gam[MpcLds::tri(i, j) * NX + r], L.usol[j], a);
+        L.xi[e] = a;
+    }
+    __syncthreads();
+    WIDE_STAMP(9);
+    if (st && tid == 0) st[10] = (unsigned long long)iters;
+#undef WIDE_STAMP
+    if (iters_out) *iters_out = iters;
+    return status;
+}
+
+template <int NX>
+__global__ __launch_bounds__(WIDE_THREADS) void mpc_qp_wide_kernel(MpcQpArgs a) {
+    extern __shared__ __align__(16) double mpc_lds[];
+    const int prob = blockIdx.x, tid = threadIdx.x;
+    if (prob >= a.nb) return;
+    const int Nc = a.c.Nc, n = Nc + 1, mt = 4 * Nc + 2;
+    WideLds L;
+    L.carve(mpc_lds, Nc, NX);
+    for (int e = tid; e < Nc * NX * NX; e += WIDE_THREADS) L.Ak[e] = a.lA[(size_t)prob * Nc * NX * NX + e];
+    for (int e = tid; e < Nc * NX; e += WIDE_THREADS) {
+        L.Bk[e] = a.lB[(size_t)prob * Nc * NX + e];
+        L.Ck[e] = a.lC[(size_t)prob * Nc * NX + e];
+        L.Xs[e] = a.Xs[(size_t)prob * Nc * NX + e];
+    }
+    for (int e = tid; e < Nc; e += WIDE_THREADS) L.Us[e] = a.Us[(size_t)prob * Nc + e];
+    for (int e = tid; e < NX; e += WIDE_THREADS) L.x0[e] = a.x0[(size_t)prob * NX + e];
+    __syncthreads();
+    WideDump dump{a.Ge ? a.Ge + (size_t)prob * n * n : nullptr, a.Fe ? a.Fe + (size_t)prob * n : nullptr,
+                  a.Le ? a.Le + (size_t)prob * mt * n : nullptr, a.hv ? a.hv + (size_t)prob * mt : nullptr};
+    const bool want_dump = a.Ge || a.Fe || a.Le || a.hv;
+    const int st = wide_solve<NX>(a.c, L, a.ymeas ? a.ymeas[prob] : 0.0, nullptr, want_dump ? &dump : nullptr,
+                                  a.stamps ? a.stamps + (size_t)prob * 12 : nullptr);
+    if (a.u) for (int e = tid; e < Nc; e += WIDE_THREADS) a.u[(size_t)prob * Nc + e] = L.usol[e];
+    if (a.xpred) for (int e = tid; e < Nc * NX; e += WIDE_THREADS) a.xpred[(size_t)prob * Nc * NX + e] = L.xi[e];
+    if (tid == 0) {
+        if (a.eps) a.eps[prob] = L.usol[Nc];
+        if (a.status) a.status[prob] = st;
+    }
+}
+
+template <int NX>
+__global__ __launch_bounds__(WIDE_THREADS) void mpc_solve_wide_kernel(CtrlDev d, RunPtrs rp, int it, int k) {
+    extern __shared__ __align__(16) double mpc_lds[];
+    const int gid = blockIdx.x, tid = threadIdx.x;
+    const int count = it == 0 ? d.B : min(d.nact[it], d.B);
+    if (gid >= count) return;
+    const int b = it == 0 ? gid : d.act[(size_t)it * d.B + gid];
+    const int Nc = d.Nc, ntot = d.n_sim + Nc;
+    WideLds L;
+    L.carve(mpc_lds, Nc, NX);
+    for (int e = tid; e < Nc * NX * NX; e += WIDE_THREADS) L.Ak[e] = (double)d.A32[(size_t)b * Nc * NX * NX + e];
+    for (int e = tid; e < Nc * NX; e += WIDE_THREADS) {
+        L.Bk[e] = (double)d.B32[(size_t)b * Nc * NX + e];
+        L.Ck[e] = (double)d.C32[(size_t)b * Nc * NX + e];
+        const int i = e / NX, r = e % NX;
+        L.Xs[e] = rp.Xs[((size_t)b * ntot + (k + 1 + i)) * NX + r];
+    }
+    for (int e = tid; e < Nc; e += WIDE_THREADS) {
+        L.Us[e] = rp.Us[(size_t)b * ntot + k + e];
+        L.uold[e] = d.uplan[(size_t)b * Nc + e];
+    }
+    for (int e = tid; e < NX; e += WIDE_THREADS) L.x0[e] = d.x0n[(size_t)b * NX + e];
+    __syncthreads();
+    int qp_it = 0;
+    const int st = wide_solve<NX>(d.c, L, d.ymeas[b], &qp_it, nullptr);
+    double du = 0.0;
+    for (int e = tid; e < Nc; e += WIDE_THREADS) {
+        const double un = L.usol[e], dd = un - L.uold[e];
+        du += dd * dd;
+        d.uplan[(size_t)b * Nc + e] = un;
+        d.us32[(size_t)b * Nc + e] = (float)un;
+    }
+    for (int e = tid; e < Nc * NX; e += WIDE_THREADS) {
+        const double xv = L.xi[e];
+        d.xpred[(size_t)b * Nc * NX + e] = xv;
+        d.xc32[(size_t)b * Nc * NX + e] = (float)xv;
+        d.xs32[(size_t)b * Nc * NX + e] = e < NX ? (float)L.x0[e] : (float)L.xi[e - NX];
+    }
+    if (tid < 64) {                                 // Nc <= 63: the plan's entries all sit in wave 0
+        du = wave_sum(du);
+        if (tid == 0) {
+            d.eps[b] = L.usol[Nc];
+            d.cnt[b] = it + 1;
+            if (st != 0) atomicAdd(d.qp_fail, 1ull);
+            d.qp_stat[2 * b] += 1u;
+            d.qp_stat[2 * b + 1] += (unsigned)qp_it;
+            if (it + 1 < d.maxit && !(sqrt(du) < d.tol)) {
+                const int pos = atomicAdd(&d.nact[it + 1], 1);
+                d.act[(size_t)(it + 1) * d.B + pos] = b;
+            }
+        }
+    }
+}
+
+// host side (mpc_wide.hip)
+bool mpc_wide_applies(int Nc, int nx, int mode, int slack);
+int launch_mpc_qp_wide(const MpcQpArgs& a, hipStream_t s);
+int launch_mpc_solve_wide(const CtrlDev& d, const RunPtrs& rp, int it, int k, hipStream_t s);
+
+}  // namespace nmpc

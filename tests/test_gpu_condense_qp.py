@@ -120,24 +120,26 @@ def test_qp_special_cases():
         nmpc_amd.solve_qp(np.diag([1.0, -1.0, 1.0]), qv)
 
 
-def test_mpc_qp_vs_oracle(enc, omodel):
-    """Assembly (G, F, L, h of NMPC_test.py:211-226) and solution of the condensed QP."""
+@pytest.mark.parametrize("Nc,ntest", [(10, 48), (30, 12), (50, 10)])
+def test_mpc_qp_vs_oracle(enc, omodel, Nc, ntest):
+    """Assembly (G, F, L, h of NMPC_test.py:211-226) and solution of the condensed QP; horizons 30 and 50
+    run on the long-horizon kernels (one workgroup per controller)."""
     import nmpc_amd
     s = disc_setup(omodel)
-    Nc, nx, nu, ny = 10, 2, 1, 1
+    nx, nu, ny = 2, 1, 1
     rng = np.random.default_rng(1)
     nodes, weights = olpv.merge_nodes(*olpv.quad_nodes("simpson", 20))
     Psi = omu.getPsi(Nc, s["R"]); Om = omu.getOmega(Nc, s["Q"])
     D, E, M, c = omu.getDEMc_out(s["ymin"], s["ymax"], s["umin"], s["umax"], Nc, ny, nu)
     ins, outs = [], []
-    for t in range(48):
+    for t in range(ntest):
         x0 = rng.uniform(-2, 2, 2); xs = rng.uniform(-2, 2, (Nc, 2)); u = rng.uniform(-2.5, 2.5, (Nc, 1)); xc = rng.uniform(-2, 2, (Nc, 2))
         A, B, C = olpv.embed(omodel, xs, u, nodes, weights, xc=xc)
         Xs = np.tile(rng.uniform(-2, 2, 2), Nc); Us = np.tile(rng.uniform(-1, 1), Nc); ym = rng.uniform(-3, 3)
         ins.append((A.reshape(-1, 2), B.reshape(-1, 1), C.reshape(-1, 2), x0, ym, Xs, Us))
         outs.append(omq(*ins[-1], omodel.f0, omodel.h0, Psi, Om, D, E, M, c, Nc, nx, nu, ny, s["rho"]))
     st = lambda i: np.stack([x[i] for x in ins])
-    for gs in ("64", "16"):
+    for gs in (("64", "16") if Nc <= 15 else ("64",)):
         import os
         os.environ["NMPC_MPC_GS"] = gs
         r = nmpc_amd.mpc_qp(st(0), st(1), st(2), st(3), st(4), st(5), st(6), omodel.f0, omodel.h0, s["Q"], s["R"], s["rho"],
