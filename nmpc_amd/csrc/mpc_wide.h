@@ -2,21 +2,29 @@
 // long-horizon runs use Nc = 50): one WORKGROUP of four wavefronts per controller instead of one wavefront.
 //
 // A QP with n = Nc + 1 variables and 4 Nc + 2 rows keeps a single wavefront busy for about a million cycles
-// (every phase is bound by that one wave's instruction issue), so here the row-parallel phases run on all
-// 256 lanes and the storage is cut to what the structure of the problem needs:
+// (every phase is bound by that one wave's instruction issue and LDS latency), so here the row-parallel
+// phases run on all 256 lanes and the storage is cut to what the structure of the problem needs:
 //   * the rows come in pairs  -a'u - eps <= h-,  +a'u - eps <= h+  (input bounds: a = e_i; output bounds:
 //     a = (C_i Gamma_{i,:})'), and the Hessian is blkdiag(G, rho), so in the solver's coordinates
 //     zt = L'z both rows of a pair have the normals [+-alpha; 1/sqrt(rho)] with ONE vector
 //     alpha = L_G^-1 a: the pair table Al[k][pair] holds alpha, half the rows of the dense formulation,
 //     and the slack variable never enters a product;
-//   * lane 2 p + h owns row h of pair p: its slack lives in a register, every Nc-long dot product of a pair
-//     is split between the pair's two lanes and combined with one DPP swap;
-//   * the small sequential parts of the dual active-set iteration (triangular solves with the working
-//     set's factor, step lengths, the decision which row enters or leaves) are computed by every wave
-//     redundantly from the same LDS data, bit for bit the same, which leaves two workgroup barriers per
-//     iteration (candidate search, Gram column of the candidate);
-//   * the Cholesky factorisation of G runs in one wave with one matrix row per lane in registers (pivot
-//     column through v_readlane) while the other waves build the right-hand sides.
+//   * lane 2 p + h owns row h of pair p and keeps the entries k = 2 m + h of alpha_p in REGISTERS (they do not
+//     change during the iteration): every Nc-long dot product of a pair is split between the pair's two
+//     lanes, reads only its broadcast operand from LDS with all loads in flight at once, and is combined
+//     with one DPP swap;
+//   * the working set's factor is kept as its INVERSE M = Lw^-1 (appending a row costs the vector r that the
+//     step computes anyway), so the two triangular solves of an iteration are two mat-vec products
+//     whose lanes do not wait for each other;
+//   * the small sequential parts of the dual active-set iteration (these products, step lengths, the
+//     decision which row enters or leaves) are computed by every wave redundantly from the same LDS data,
+//     bit for bit the same, which leaves two workgroup barriers per iteration (candidate search, Gram
+//     column of the candidate);
+//   * the Cholesky factorisation of G and the final back substitution run in one wave with one matrix row /
+//     column per lane in registers (pivots through v_readlane); the forward substitution of all pair
+//     columns is a fully unrolled right-looking sweep over the registers.
+// KH = rows of the pair table per lane (horizons up to 2 KH): the unrolled loops run to 2 KH without
+// tests, the LDS arrays are padded with zero rows up to there.
 // The algorithm is the Goldfarb-Idnani iteration of qp_gi.h (same pivoting rule, tolerances and status
 // codes); only the data layout and the work distribution differ.
 #pragma once
@@ -30,21 +38,23 @@ __host__ __device__ inline int wide_npairs(int Nc) { return 2 * Nc + 1; }
 // Columns of the pair table: the pairs, then the linear term; padded to 16 mod 32 so that the two lanes of a
 // pair, which read rows k and k+1 of the table in the same instruction, fall into different halves of the banks.
 __host__ __device__ inline int wide_cols(int Nc) { return ((wide_npairs(Nc) + 1 + 15) / 32) * 32 + 16; }
+// instantiated: nx = 2 with KH 16 / 25 / 32 (horizons to 32 / 50 / 63), nx = 3, 4 with KH 32
+__host__ __device__ inline int wide_kh(int Nc, int nx) { return nx != 2 ? 32 : (Nc <= 32 ? 16 : (Nc <= 50 ? 25 : 32)); }
 
 struct WideLds {
-    double *Lm, *Lw, *Al, *Gam, *Ak, *Bk, *Ck, *qd, *xi, *x0, *Xs, *Us, *uold, *hv, *invdL, *invdW, *Dp, *usol, *avec, *red;
+    double *Lm, *Lw, *Mi, *Al, *Gam, *Ak, *Bk, *Ck, *qd, *xi, *x0, *Xs, *Us, *uold, *hv, *invdL, *invdW, *Dp, *usol, *wbuf, *red;
     int* Wtab;
-    __host__ __device__ static int doubles(int Nc, int nx) {
-        const int n = Nc + 1, NPc = wide_cols(Nc);
-        return Nc * Nc + n * n + Nc * NPc + Nc * (Nc + 1) / 2 * nx + Nc * nx * nx + 5 * Nc * nx + 4 + 2 * Nc + 2 * wide_npairs(Nc) + 2 +
-               Nc + n + NPc + n + 4 * 64 + 32 + 2 * n + 2;
+    __host__ __device__ static int doubles(int Nc, int nx, int KH) {
+        const int n = Nc + 1, NPc = wide_cols(Nc), R = 2 * KH;
+        return R * Nc + 2 * n * n + R * NPc + Nc * (Nc + 1) / 2 * nx + Nc * nx * nx + 5 * Nc * nx + 4 + 2 * Nc + 2 * wide_npairs(Nc) + 2 +
+               R + n + NPc + n + 3 * 4 * 64 + 32 + 2 * n + 2;
     }
-    __device__ void carve(double* p, int Nc, int nx) {
-        const int n = Nc + 1, NPc = wide_cols(Nc);
-        Lm = p; p += Nc * Nc; Lw = p; p += n * n; Al = p; p += Nc * NPc; Gam = p; p += Nc * (Nc + 1) / 2 * nx;
+    __device__ void carve(double* p, int Nc, int nx, int KH) {
+        const int n = Nc + 1, NPc = wide_cols(Nc), R = 2 * KH;
+        Lm = p; p += R * Nc; Lw = p; p += n * n; Mi = p; p += n * n; Al = p; p += R * NPc; Gam = p; p += Nc * (Nc + 1) / 2 * nx;
         Ak = p; p += Nc * nx * nx; Bk = p; p += Nc * nx; Ck = p; p += Nc * nx; qd = p; p += Nc * nx; xi = p; p += Nc * nx;
         Xs = p; p += Nc * nx; x0 = p; p += 4; Us = p; p += Nc; uold = p; p += Nc; hv = p; p += 2 * wide_npairs(Nc) + 2;
-        invdL = p; p += Nc; invdW = p; p += n; Dp = p; p += NPc; usol = p; p += n; avec = p; p += 4 * 64; red = p; p += 32;
+        invdL = p; p += R; invdW = p; p += n; Dp = p; p += NPc; usol = p; p += n; wbuf = p; p += 3 * 4 * 64; red = p; p += 32;
         Wtab = reinterpret_cast<int*>(p);     // n pair ids, then n signs as doubles behind them
     }
 };
@@ -52,32 +62,36 @@ struct WideLds {
 // red: [0..3] score, [4..7] slack of the candidate, [8..11] row (as double), [12] sp after a drop, [13] flag
 __device__ __forceinline__ double dpp_swap1(double v) { return dpp_d<DPP_XOR1>(v); }
 
-// Cholesky of the leading n x n block of Lm (row-major, ld n, lower triangle valid), one wave, row i in the
-// registers of lane i.  Rows take the update over their whole tail: entries right of the diagonal are never read.
+// Cholesky of the leading n x n block of Lm (row-major, ld n, lower triangle valid; rows n .. NMAX-1 exist and
+// are zero), one wave, row i in the registers of lane i.  Rows take the update over their whole tail: entries
+// right of the diagonal are never read.  invd[j] = 1 / L[j][j].
 template <int NMAX>
-__device__ __attribute__((noinline)) bool wide_chol_regs(double* Lm, double* invd, int n) {
+__device__ __forceinline__ bool wide_chol_regs(double* Lm, double* invd, int n) {
     const int lane = threadIdx.x & 63;
     double row[NMAX];
+    const int lr = lane < n ? lane : 0;
 #pragma unroll
-    for (int c = 0; c < NMAX; ++c) row[c] = (lane < n && c <= lane) ? Lm[lane * n + c] : 0.0;
+    for (int c = 0; c < NMAX; ++c) {
+        const double v = Lm[lr * n + (c < n ? c : 0)];
+        row[c] = (lane < n && c <= lane) ? v : 0.0;
+    }
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < NMAX; ++j) {
-        if (j < n) {
+        if (j < n) {                                  // uniform
             const double d = readlane_d(row[j], j);
             if (!(d > 0.0)) ok = false;
             const double inv = rsqrt_d(d > 0.0 ? d : 1.0);
             row[j] *= inv;
             if (lane == 0) invd[j] = inv;
 #pragma unroll
-            for (int c = j + 1; c < NMAX; ++c)
-                if (c < n) row[c] = fma(-row[j], readlane_d(row[j], c), row[c]);
+            for (int c = j + 1; c < NMAX; ++c) row[c] = fma(-row[j], readlane_d(row[j], c), row[c]);
         }
     }
     if (lane < n) {
 #pragma unroll
         for (int c = 0; c < NMAX; ++c)
-            if (c <= lane) Lm[lane * n + c] = row[c];
+            if (c <= lane && c < n) Lm[lane * n + c] = row[c];
     }
     return ok;
 }
@@ -86,19 +100,22 @@ struct WideDump { double *Ge, *Fe, *Le, *hv; };
 
 // On entry Ak, Bk, Ck, x0, Xs, Us are loaded (and a barrier passed).  On exit usol[0..Nc) = u, usol[Nc] = eps,
 // xi = predicted states; returns the solver status (uniform), *iters_out the active-set iterations.
-template <int NX>
+// st (diagnostics): clock stamps [0] entry, after [1] recurrences [2] qd [3] Hessian / rows [4] Cholesky
+// [5] transform [6] slack init [7] active-set loop [8] recovery of z [9] prediction; [10] iterations;
+// [11] the whole solve in ticks of the constant 100 MHz clock.
+template <int NX, int KH>
 __device__ __forceinline__ int wide_solve(const MpcConst& c, WideLds& L, double ymeas, int* iters_out, const WideDump* dump,
                                           unsigned long long* st = nullptr) {
-    // st (diagnostics): 12 clock stamps: [0] entry, after [1] recurrences [2] qd [3] Hessian / rows [4] Cholesky
-    // [5] transform [6] slack init [7] active-set loop [8] recovery of z [9] prediction
+    constexpr int R = 2 * KH;
     const int tid = threadIdx.x, lane = tid & 63;
 #define WIDE_STAMP(i) do { if (st && tid == 0) st[i] = __builtin_amdgcn_s_memtime(); } while (0)
     WIDE_STAMP(0);
+    const unsigned long long rt0 = st ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Nc = c.Nc, n = Nc + 1, NP = wide_npairs(Nc), NPc = wide_cols(Nc);
     double* Al = L.Al;
     // ---- P1: wave 0 runs the condensing recurrences (lane j < Nc: column j of Gamma; lane Nc: free response),
-    //          the other waves clear the pair table
+    //          the other waves clear the pair table, the inverse factor and the padding rows of Lm
     if (wave == 0) {
         const int j = lane;
         const bool col = j < Nc, fr = j == Nc;
@@ -148,7 +165,12 @@ __device__ __forceinline__ int wide_solve(const MpcConst& c, WideLds& L, double 
             emit(d);
         }
     } else {
-        for (int e = tid - 64; e < Nc * NPc; e += WIDE_THREADS - 64) Al[e] = 0.0;
+        const int t3 = tid - 64, n3 = WIDE_THREADS - 64;
+        for (int e = t3; e < R * NPc; e += n3) Al[e] = 0.0;
+        for (int e = t3; e < n * n; e += n3) L.Mi[e] = 0.0;
+        for (int e = Nc * Nc + t3; e < R * Nc; e += n3) L.Lm[e] = 0.0;
+        for (int e = Nc + t3; e < R; e += n3) L.invdL[e] = 0.0;
+        for (int e = t3; e < 3 * 4 * 64; e += n3) L.wbuf[e] = 0.0;
     }
     __syncthreads();
     WIDE_STAMP(1);
@@ -172,6 +194,7 @@ __device__ __forceinline__ int wide_solve(const MpcConst& c, WideLds& L, double 
         const int b_ = t - a_ * (a_ + 1) / 2;
         double g = 0.0, f = 0.0;
         int ta = MpcLds::tri(a_, a_), tb = MpcLds::tri(a_, b_);
+#pragma unroll 4
         for (int i = a_; i < Nc; ++i) {
             double ga[NX], gb[NX];
 #pragma unroll
@@ -199,10 +222,10 @@ __device__ __forceinline__ int wide_solve(const MpcConst& c, WideLds& L, double 
     // ---- P4: right-hand sides; P5: Cholesky of G in wave 0 beside it (after the optional dumps)
     auto fill_hv = [&](int first, int stride) {
         for (int row = first; row < 2 * NP; row += stride) {
-            const int p = row >> 1, h = row & 1;
+            const int p = row >> 1, hh = row & 1;
             double hval;
             if (!(p & 1) && p < 2 * Nc) {
-                hval = h ? c.umax : -c.umin;
+                hval = hh ? c.umax : -c.umin;
             } else {
                 const int blk = p == 2 * Nc ? Nc : (p - 1) >> 1;
                 double yv = ymeas;
@@ -211,12 +234,11 @@ __device__ __forceinline__ int wide_solve(const MpcConst& c, WideLds& L, double 
 #pragma unroll
                     for (int r = 0; r < NX; ++r) yv = fma(L.Ck[(blk - 1) * NX + r], L.xi[(blk - 1) * NX + r], yv);
                 }
-                hval = h ? c.ymax - yv : yv - c.ymin;
+                hval = hh ? c.ymax - yv : yv - c.ymin;
             }
             L.hv[row] = hval;
         }
     };
-    bool chol_ok = true;
     if (dump) {
         fill_hv(tid, WIDE_THREADS);
         __syncthreads();
@@ -232,39 +254,48 @@ __device__ __forceinline__ int wide_solve(const MpcConst& c, WideLds& L, double 
         }
         if (dump->hv) for (int e = tid; e < mt; e += WIDE_THREADS) dump->hv[e] = L.hv[e];
         __syncthreads();
-        if (wave == 0) chol_ok = Nc <= 32 ? wide_chol_regs<32>(L.Lm, L.invdL, Nc) : wide_chol_regs<64>(L.Lm, L.invdL, Nc);
-    } else if (wave == 0) {
-        chol_ok = Nc <= 32 ? wide_chol_regs<32>(L.Lm, L.invdL, Nc) : wide_chol_regs<64>(L.Lm, L.invdL, Nc);
-    } else {
+    }
+    if (wave == 0) {
+        const bool chol_ok = wide_chol_regs<R>(L.Lm, L.invdL, Nc);
+        if (tid == 0) L.red[13] = chol_ok ? 1.0 : 0.0;
+    } else if (!dump) {
         fill_hv(tid - 64, WIDE_THREADS - 64);
     }
-    if (tid == 0) L.red[13] = chol_ok ? 1.0 : 0.0;
     __syncthreads();
     if (L.red[13] == 0.0) {
         if (iters_out) *iters_out = 0;
         return 3;
     }
     WIDE_STAMP(4);
-    // ---- P6: alpha = L_G^-1 a for every pair, and zt = -L_G^-1 F (column NP).  Lane 2 i + h works on
-    //          column i; the dot over l < k is split by the parity of l between the two lanes.
+    // ---- P6: alpha = L_G^-1 a for every pair and zt = -L_G^-1 F (column NP): right-looking forward
+    //          substitution.  Lane 2 i + h holds rows k = 2 m + h of column i in areg[m]; row l's solution is
+    //          formed by the lane that owns it, passed to its partner, and both update their later rows.
     const int ci = tid >> 1, h = tid & 1;
     const bool has_col = ci <= NP;
     const int cc = has_col ? ci : NP;
+    double areg[KH];
     {
         const double sgn = ci == NP ? -1.0 : 1.0;            // the linear term q enters as right-hand side -q
-        double yprev = 0.0;
-        for (int k = 0; k < Nc; ++k) {
-            double part = 0.0;
-            const double* Lk = L.Lm + k * Nc;
-#pragma unroll 4
-            for (int l = h; l < k - 1; l += 2) part = fma(Lk[l], Al[l * NPc + cc], part);
-            part += dpp_swap1(part);
-            double v = sgn * Al[k * NPc + cc] - part;
-            if (k > 0) v = fma(-Lk[k - 1], yprev, v);
-            const double y = v * L.invdL[k];
-            // lane h = 0 stores; the entry is read back two rows later at the earliest (same wave: in order)
-            if (has_col && h == 0) Al[k * NPc + cc] = y;
-            yprev = y;
+        const double dreg = L.invdL[lane < R ? lane : 0];    // lane l: 1 / L[l][l]
+#pragma unroll
+        for (int m = 0; m < KH; ++m) areg[m] = sgn * Al[(2 * m + h) * NPc + cc];
+        const double* Lh = L.Lm + h * Nc;                    // row 2 m + h of L starts at Lh + 2 m Nc
+#pragma unroll
+        for (int l = 0; l < R; ++l) {
+            if (l >= Nc) continue;                          // uniform; padding rows have nothing to solve
+            const int ml = l >> 1, hl = l & 1;
+            const double ym = areg[ml] * readlane_d(dreg, l);
+            const double yo = dpp_swap1(ym);
+            const bool mine = h == hl;
+            const double y = mine ? ym : yo;
+            areg[ml] = mine ? y : areg[ml];
+            if (mine && has_col && l < Nc) Al[l * NPc + cc] = y;
+#pragma unroll
+            for (int m = (l + 1) >> 1; m < KH; ++m) {
+                double coef = Lh[2 * m * Nc + l];
+                if (2 * m == l) coef = h ? coef : 0.0;       // row 2 m + 0 = l is the pivot row itself
+                areg[m] = fma(-coef, y, areg[m]);
+            }
         }
     }
     __syncthreads();
@@ -272,14 +303,23 @@ __device__ __forceinline__ int wide_solve(const MpcConst& c, WideLds& L, double 
     // ---- P7: slacks s = h + nt . zt_unc (the slack component of zt_unc is zero).  Lane 2 p + h owns row h of pair p.
     const int row = tid, pi = tid >> 1;
     const bool has_row = pi < NP;
-    const int pc = has_row ? pi : NP - 1;
     const double sigma = 1.0 / sqrt(c.rho), sig2 = 1.0 / c.rho;
     double s = 0.0, iscale = 1.0;
-    {
-        double part = 0.0;
-#pragma unroll 4
-        for (int k = h; k < Nc; k += 2) part = fma(Al[k * NPc + pc], Al[k * NPc + NP], part);
+    auto pair_dot = [&](const double* op, int stride) {      // sum_k alpha_own[k] op[k stride], both lanes of the pair
+        double p0 = 0.0, p1 = 0.0;
+        const double* o = op + h * stride;
+#pragma unroll
+        for (int m = 0; m + 1 < KH; m += 2) {
+            p0 = fma(areg[m], o[2 * m * stride], p0);
+            p1 = fma(areg[m + 1], o[(2 * m + 2) * stride], p1);
+        }
+        if (KH & 1) p0 = fma(areg[KH - 1], o[2 * (KH - 1) * stride], p0);
+        double part = p0 + p1;
         part += dpp_swap1(part);
+        return part;
+    };
+    {
+        const double part = pair_dot(Al + NP, NPc);
         if (has_row) {
             const double hval = L.hv[row];
             iscale = 1.0 / (1.0 + fabs(hval));
@@ -293,7 +333,10 @@ __device__ __forceinline__ int wide_solve(const MpcConst& c, WideLds& L, double 
     int wpj = 0;
     bool inW = false;
     const int max_iter = 10 * (n + 2 * NP) + 20;
-    double* avec = L.avec + wave * 64;
+    double* avec = L.wbuf + wave * 64;            // this wave's copies: direction, kp, l
+    double* kpb = L.wbuf + (4 + wave) * 64;
+    double* lb = L.wbuf + (8 + wave) * 64;
+    double* Mi = L.Mi;
     for (;;) {
         double best = QP_INF; int bi = 0x7fffffff;
         if (has_row && !inW) { best = s * iscale; bi = row; }
@@ -311,10 +354,7 @@ __device__ __forceinline__ int wide_solve(const MpcConst& c, WideLds& L, double 
         const int pp = p >> 1;
         const double sgp = (p & 1) ? -1.0 : 1.0;
         {   // Gram column of the candidate: Dp[i] = alpha_i . alpha_p
-            double part = 0.0;
-#pragma unroll 4
-            for (int k = h; k < Nc; k += 2) part = fma(Al[k * NPc + pc], Al[k * NPc + pp], part);
-            part += dpp_swap1(part);
+            const double part = pair_dot(Al + pp, NPc);
             if (has_row && h == 0) L.Dp[pi] = part;
         }
         __syncthreads();
@@ -322,35 +362,28 @@ __device__ __forceinline__ int wide_solve(const MpcConst& c, WideLds& L, double 
         double lam_p = 0.0;
         for (;;) {
             if (++iters > max_iter) { status = 1; break; }
-            const int glq = lane < q ? lane : 0;
-            double kp = lane < q ? fma(wsgj * sgp, L.Dp[wpj], sig2) : 0.0;
-            // l = Lw^-1 kp
-            double v = kp, lj = 0.0;
-            const double invw = L.invdW[glq];
+            const int iq = lane < q ? lane : 0;
+            // l = Lw^-1 kp = M kp,  r = Lw^-T l = M' l   (M lower triangular, zero above the diagonal)
+            g_sync();
+            kpb[lane] = lane < q ? fma(wsgj * sgp, L.Dp[wpj], sig2) : 0.0;
+            g_sync();
+            double lj = 0.0;
             {
-                double lnext = L.Lw[glq * n];
-                for (int i = 0; i < q; ++i) {
-                    const double lcur = lnext;
-                    if (i + 1 < q) lnext = L.Lw[glq * n + i + 1];
-                    const double li = readlane_d(v, i) * readlane_d(invw, i);
-                    if (lane == i) lj = li;
-                    if (lane > i && lane < q) v = fma(-lcur, li, v);
-                }
+                const double* mr = Mi + iq * n;
+#pragma unroll 4
+                for (int j = 0; j < q; ++j) lj = fma(mr[j], kpb[j], lj);
             }
-            const double dd = kpp - wave_sum(lane < q ? lj * lj : 0.0);
-            // r = Lw^-T l
-            v = lj;
+            if (lane >= q) lj = 0.0;
+            const double dd = kpp - wave_sum(lj * lj);
+            lb[lane] = lj;
+            g_sync();
             double rj = 0.0;
             {
-                double lnext = q > 0 ? L.Lw[(q - 1) * n + glq] : 0.0;
-                for (int i = q - 1; i >= 0; --i) {
-                    const double lcur = lnext;
-                    if (i > 0) lnext = L.Lw[(i - 1) * n + glq];
-                    const double ri = readlane_d(v, i) * readlane_d(invw, i);
-                    if (lane == i) rj = ri;
-                    if (lane < i) v = fma(-lcur, ri, v);
-                }
+                const double* mc = Mi + iq;
+#pragma unroll 4
+                for (int i = 0; i < q; ++i) rj = fma(mc[i * n], lb[i], rj);
             }
+            if (lane >= q) rj = 0.0;
             double t1 = QP_INF; int kd = 0x7fffffff;
             if (lane < q && rj > 1e-13) { t1 = lamj / rj; kd = lane; }
             g_argmin<64>(t1, kd);
@@ -361,31 +394,24 @@ __device__ __forceinline__ int wide_solve(const MpcConst& c, WideLds& L, double 
             if (primal) {
                 // direction in zt coordinates, components k < Nc on lane k (every wave its own copy); the slack
                 // component is sigma (1 - sum r)
-                const int kr = lane < Nc ? lane : Nc - 1;
-                double a = sgp * Al[kr * NPc + pp];
+                const int kr = lane < Nc ? lane : 0;
+                const double* ak = Al + kr * NPc;
+                double a = sgp * ak[pp];
                 const double rs = rj * wsgj;
-                for (int j = 0; j < q; ++j) a = fma(-Al[kr * NPc + __builtin_amdgcn_readlane(wpj, j)], readlane_d(rs, j), a);
-                const double vn = sigma * (1.0 - wave_sum(lane < q ? rj : 0.0));
-                g_sync();
+#pragma unroll 4
+                for (int j = 0; j < q; ++j) a = fma(-ak[__builtin_amdgcn_readlane(wpj, j)], readlane_d(rs, j), a);
+                const double vn = sigma * (1.0 - wave_sum(rj));
                 avec[lane] = lane < Nc ? a : 0.0;
                 g_sync();
-                double part = 0.0;
-#pragma unroll 4
-                for (int k = h; k < Nc; k += 2) part = fma(Al[k * NPc + pc], avec[k], part);
-                part += dpp_swap1(part);
+                const double part = pair_dot(avec, 1);
                 if (has_row) s = fma(t, (h ? -part : part) + sigma * vn, s);
             }
             if (lane < q) lamj -= t * rj;
             lam_p += t;
             if (primal && t2 <= t1) {          // full step: p joins the working set at position q
-                g_sync();
-                if (lane < q) L.Lw[q * n + lane] = lj;
-                if (lane == q) {
-                    const double dl = sqrt(dd);
-                    L.Lw[q * n + q] = dl; L.invdW[q] = 1.0 / dl;
-                    lamj = lam_p; wpj = pp; wsgj = sgp;
-                }
-                g_sync();
+                const double dl = sqrt(dd), idl = 1.0 / dl;
+                if (lane < n) Mi[q * n + lane] = lane < q ? -rj * idl : (lane == q ? idl : 0.0);
+                if (lane == q) { lamj = lam_p; wpj = pp; wsgj = sgp; }
                 if (has_row && row == p) { s = 0.0; inW = true; }
                 ++q;
                 break;
@@ -399,10 +425,11 @@ __device__ __forceinline__ int wide_solve(const MpcConst& c, WideLds& L, double 
                 if (lane >= kd && lane < q - 1) { lamj = lnext; wpj = wnext; wsgj = snext; }
                 --q;
                 if (lane >= q) { lamj = 0.0; wpj = 0; wsgj = 1.0; }
-                // rebuild Lw = chol(K_WW), K_ab = sg_a sg_b alpha_a . alpha_b + 1/rho, by the whole workgroup
+                // rebuild: K_ab = sg_a sg_b alpha_a . alpha_b + 1/rho by the whole workgroup, Lw = chol(K) and
+                // M = Lw^-1 by wave 0
                 double* Wsg = reinterpret_cast<double*>(L.Wtab + 2 * ((n + 1) / 2));
                 if (has_row && row == p) L.red[12] = s;
-                __syncthreads();               // every wave is done with the old factor
+                __syncthreads();               // every wave is done with the old inverse factor
                 if (wave == 0 && lane < q) { L.Wtab[lane] = wpj; Wsg[lane] = wsgj; }
                 __syncthreads();
                 for (int e = tid; e < q * (q + 1) / 2; e += WIDE_THREADS) {
@@ -419,6 +446,19 @@ __device__ __forceinline__ int wide_solve(const MpcConst& c, WideLds& L, double 
                 __syncthreads();
                 if (wave == 0) {
                     const bool ok = chol_rows_lds(L.Lw, q, n, L.invdW);
+                    g_sync();
+                    if (ok && lane < q) {       // column `lane` of M = Lw^-1 by forward substitution
+                        for (int i = 0; i < q; ++i) {
+                            double x = 0.0;
+                            if (i == lane) x = L.invdW[i];
+                            else if (i > lane) {
+                                double acc = 0.0;
+                                for (int k = lane; k < i; ++k) acc = fma(L.Lw[i * n + k], Mi[k * n + lane], acc);
+                                x = -acc * L.invdW[i];
+                            }
+                            Mi[i * n + lane] = x;
+                        }
+                    }
                     if (lane == 0) L.red[13] = ok ? 1.0 : 0.0;
                 }
                 __syncthreads();
@@ -428,23 +468,29 @@ __device__ __forceinline__ int wide_solve(const MpcConst& c, WideLds& L, double 
         }
         if (status) break;
     }
-    // ---- P9: z from the multipliers: L' z = zt_unc + Nt_W lam; wave 0 solves, the slack variable is separate
+    // ---- P9: z from the multipliers: L' z = zt_unc + Nt_W lam; wave 0 solves with column k of L in lane k's
+    //          registers, the slack variable is separate
     __syncthreads();
     WIDE_STAMP(7);
     if (wave == 0) {
-        const int kr = lane < Nc ? lane : Nc - 1;
-        double v = Al[kr * NPc + NP];
+        const int kr = lane < Nc ? lane : 0;
+        double creg[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) creg[i] = L.Lm[i * Nc + kr];          // L[i][k]; rows >= Nc are zero
+        const double* ak = Al + kr * NPc;
+        double v = ak[NP];
         const double ls = lamj * wsgj;
-        for (int j = 0; j < q; ++j) v = fma(Al[kr * NPc + __builtin_amdgcn_readlane(wpj, j)], readlane_d(ls, j), v);
+#pragma unroll 4
+        for (int j = 0; j < q; ++j) v = fma(ak[__builtin_amdgcn_readlane(wpj, j)], readlane_d(ls, j), v);
+        if (lane >= Nc) v = 0.0;
         const double lsum = wave_sum(lane < q ? lamj : 0.0);
-        const double invl = L.invdL[kr];
-        double xres = 0.0, lnext = L.Lm[(Nc - 1) * Nc + kr];
-        for (int i = Nc - 1; i >= 0; --i) {
-            const double lcur = lnext;
-            if (i > 0) lnext = L.Lm[(i - 1) * Nc + kr];
-            const double xv = readlane_d(v, i) * readlane_d(invl, i);
+        const double invl = L.invdL[lane < R ? lane : 0];
+        double xres = 0.0;
+#pragma unroll
+        for (int i = R - 1; i >= 0; --i) {
+            const double xv = readlane_d(v, i) * readlane_d(invl, i);     // zero for the padding rows
             if (lane == i) xres = xv;
-            if (lane < i) v = fma(-lcur, xv, v);
+            v = lane < i ? fma(-creg[i], xv, v) : v;
         }
         if (lane < Nc) L.usol[lane] = xres;
         if (lane == 0) L.usol[Nc] = sig2 * lsum;
@@ -455,25 +501,26 @@ __device__ __forceinline__ int wide_solve(const MpcConst& c, WideLds& L, double 
     for (int e = tid; e < Nc * NX; e += WIDE_THREADS) {
         const int i = e / NX, r = e % NX;
         double a = L.xi[e];
+#pragma unroll 4
         for (int j = 0; j <= i; ++j) a = fma(L.Gam[MpcLds::tri(i, j) * NX + r], L.usol[j], a);
         L.xi[e] = a;
     }
     __syncthreads();
     WIDE_STAMP(9);
-    if (st && tid == 0) st[10] = (unsigned long long)iters;
+    if (st && tid == 0) { st[10] = (unsigned long long)iters; st[11] = __builtin_amdgcn_s_memrealtime() - rt0; }
 #undef WIDE_STAMP
     if (iters_out) *iters_out = iters;
     return status;
 }
 
-template <int NX>
+template <int NX, int KH>
 __global__ __launch_bounds__(WIDE_THREADS) void mpc_qp_wide_kernel(MpcQpArgs a) {
     extern __shared__ __align__(16) double mpc_lds[];
     const int prob = blockIdx.x, tid = threadIdx.x;
     if (prob >= a.nb) return;
     const int Nc = a.c.Nc, n = Nc + 1, mt = 4 * Nc + 2;
     WideLds L;
-    L.carve(mpc_lds, Nc, NX);
+    L.carve(mpc_lds, Nc, NX, KH);
     for (int e = tid; e < Nc * NX * NX; e += WIDE_THREADS) L.Ak[e] = a.lA[(size_t)prob * Nc * NX * NX + e];
     for (int e = tid; e < Nc * NX; e += WIDE_THREADS) {
         L.Bk[e] = a.lB[(size_t)prob * Nc * NX + e];
@@ -486,8 +533,8 @@ __global__ __launch_bounds__(WIDE_THREADS) void mpc_qp_wide_kernel(MpcQpArgs a) 
     WideDump dump{a.Ge ? a.Ge + (size_t)prob * n * n : nullptr, a.Fe ? a.Fe + (size_t)prob * n : nullptr,
                   a.Le ? a.Le + (size_t)prob * mt * n : nullptr, a.hv ? a.hv + (size_t)prob * mt : nullptr};
     const bool want_dump = a.Ge || a.Fe || a.Le || a.hv;
-    const int st = wide_solve<NX>(a.c, L, a.ymeas ? a.ymeas[prob] : 0.0, nullptr, want_dump ? &dump : nullptr,
-                                  a.stamps ? a.stamps + (size_t)prob * 12 : nullptr);
+    const int st = wide_solve<NX, KH>(a.c, L, a.ymeas ? a.ymeas[prob] : 0.0, nullptr, want_dump ? &dump : nullptr,
+                                      a.stamps ? a.stamps + (size_t)prob * 12 : nullptr);
     if (a.u) for (int e = tid; e < Nc; e += WIDE_THREADS) a.u[(size_t)prob * Nc + e] = L.usol[e];
     if (a.xpred) for (int e = tid; e < Nc * NX; e += WIDE_THREADS) a.xpred[(size_t)prob * Nc * NX + e] = L.xi[e];
     if (tid == 0) {
@@ -496,7 +543,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void mpc_qp_wide_kernel(MpcQpArgs a) 
     }
 }
 
-template <int NX>
+template <int NX, int KH>
 __global__ __launch_bounds__(WIDE_THREADS) void mpc_solve_wide_kernel(CtrlDev d, RunPtrs rp, int it, int k) {
     extern __shared__ __align__(16) double mpc_lds[];
     const int gid = blockIdx.x, tid = threadIdx.x;
@@ -505,7 +552,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void mpc_solve_wide_kernel(CtrlDev d,
     const int b = it == 0 ? gid : d.act[(size_t)it * d.B + gid];
     const int Nc = d.Nc, ntot = d.n_sim + Nc;
     WideLds L;
-    L.carve(mpc_lds, Nc, NX);
+    L.carve(mpc_lds, Nc, NX, KH);
     for (int e = tid; e < Nc * NX * NX; e += WIDE_THREADS) L.Ak[e] = (double)d.A32[(size_t)b * Nc * NX * NX + e];
     for (int e = tid; e < Nc * NX; e += WIDE_THREADS) {
         L.Bk[e] = (double)d.B32[(size_t)b * Nc * NX + e];
@@ -520,7 +567,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void mpc_solve_wide_kernel(CtrlDev d,
     for (int e = tid; e < NX; e += WIDE_THREADS) L.x0[e] = d.x0n[(size_t)b * NX + e];
     __syncthreads();
     int qp_it = 0;
-    const int st = wide_solve<NX>(d.c, L, d.ymeas[b], &qp_it, nullptr);
+    const int st = wide_solve<NX, KH>(d.c, L, d.ymeas[b], &qp_it, nullptr);
     double du = 0.0;
     for (int e = tid; e < Nc; e += WIDE_THREADS) {
         const double un = L.usol[e], dd = un - L.uold[e];
@@ -550,9 +597,37 @@ __global__ __launch_bounds__(WIDE_THREADS) void mpc_solve_wide_kernel(CtrlDev d,
     }
 }
 
-// host side (mpc_wide.hip)
+// host side (mpc_wide.hip, mpc_wide34.hip)
 bool mpc_wide_applies(int Nc, int nx, int mode, int slack);
 int launch_mpc_qp_wide(const MpcQpArgs& a, hipStream_t s);
 int launch_mpc_solve_wide(const CtrlDev& d, const RunPtrs& rp, int it, int k, hipStream_t s);
+int launch_mpc_qp_wide_nx34(const MpcQpArgs& a, hipStream_t s);
+int launch_mpc_solve_wide_nx34(const CtrlDev& d, const RunPtrs& rp, int it, int k, hipStream_t s);
+
+template <int NX, int KH>
+static int launch_qp_wide_t(const MpcQpArgs& a, hipStream_t s) {
+    static std::atomic<unsigned long long> once{0};
+    if (first_use_on_device(once)) {
+        if (set_lds_attr(mpc_qp_wide_kernel<NX, KH>)) return 1;
+        mark_used_on_device(once);
+    }
+    const size_t lds = sizeof(double) * (size_t)WideLds::doubles(a.c.Nc, NX, KH);
+    hipLaunchKernelGGL((mpc_qp_wide_kernel<NX, KH>), dim3(a.nb), dim3(WIDE_THREADS), lds, s, a);
+    NMPC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <int NX, int KH>
+static int launch_solve_wide_t(const CtrlDev& d, const RunPtrs& rp, int it, int k, hipStream_t s) {
+    static std::atomic<unsigned long long> once{0};
+    if (first_use_on_device(once)) {
+        if (set_lds_attr(mpc_solve_wide_kernel<NX, KH>)) return 1;
+        mark_used_on_device(once);
+    }
+    const size_t lds = sizeof(double) * (size_t)WideLds::doubles(d.Nc, NX, KH);
+    hipLaunchKernelGGL((mpc_solve_wide_kernel<NX, KH>), dim3(d.B), dim3(WIDE_THREADS), lds, s, d, rp, it, k);
+    NMPC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 
 }  // namespace nmpc

@@ -1,4 +1,5 @@
-// Host side of the long-horizon condensing + QP kernels (mpc_wide.h): when they apply, and their launches.
+// Host side of the long-horizon condensing + QP kernels (mpc_wide.h): when they apply, and the launches
+// for nx = 2 (nx = 3, 4: mpc_wide34.hip).
 #include <cstdlib>
 
 #include "mpc_wide.h"
@@ -7,7 +8,8 @@ namespace nmpc {
 
 // Output feedback with the slack variable (the reference's long-horizon configuration), horizons from
 // NMPC_MPC_WIDE_MIN (default 24) up: below that a controller fits one wavefront's registers / a few KB of
-// LDS and sixteen of them share a CU.
+// LDS and sixteen of them share a CU.  Horizons whose workgroup would not fit the CU's LDS stay on the
+// one-wavefront kernels.
 bool mpc_wide_applies(int Nc, int nx, int mode, int slack) {
     static std::atomic<int> cache{-1};
     int lo = cache.load(std::memory_order_relaxed);
@@ -17,50 +19,24 @@ bool mpc_wide_applies(int Nc, int nx, int mode, int slack) {
         if (lo < 2) lo = 2;
         cache.store(lo, std::memory_order_relaxed);
     }
-    return mode == 0 && slack == 1 && nx >= 2 && nx <= 4 && Nc >= lo && Nc <= 63 &&
-           sizeof(double) * (size_t)WideLds::doubles(Nc, nx) <= 160 * 1024;
-}
-
-template <int NX>
-static int launch_qp_t(const MpcQpArgs& a, hipStream_t s) {
-    static std::atomic<unsigned long long> once{0};
-    if (first_use_on_device(once)) {
-        if (set_lds_attr(mpc_qp_wide_kernel<NX>)) return 1;
-        mark_used_on_device(once);
-    }
-    const size_t lds = sizeof(double) * (size_t)WideLds::doubles(a.c.Nc, NX);
-    hipLaunchKernelGGL((mpc_qp_wide_kernel<NX>), dim3(a.nb), dim3(WIDE_THREADS), lds, s, a);
-    NMPC_HIP_CHECK(hipGetLastError());
-    return 0;
-}
-
-template <int NX>
-static int launch_solve_t(const CtrlDev& d, const RunPtrs& rp, int it, int k, hipStream_t s) {
-    static std::atomic<unsigned long long> once{0};
-    if (first_use_on_device(once)) {
-        if (set_lds_attr(mpc_solve_wide_kernel<NX>)) return 1;
-        mark_used_on_device(once);
-    }
-    const size_t lds = sizeof(double) * (size_t)WideLds::doubles(d.Nc, NX);
-    hipLaunchKernelGGL((mpc_solve_wide_kernel<NX>), dim3(d.B), dim3(WIDE_THREADS), lds, s, d, rp, it, k);
-    NMPC_HIP_CHECK(hipGetLastError());
-    return 0;
+    if (!(mode == 0 && slack == 1 && nx >= 2 && nx <= 4 && Nc >= lo && Nc <= 63)) return false;
+    return sizeof(double) * (size_t)WideLds::doubles(Nc, nx, wide_kh(Nc, nx)) <= 160 * 1024;
 }
 
 int launch_mpc_qp_wide(const MpcQpArgs& a, hipStream_t s) {
-    if (a.nx == 2) return launch_qp_t<2>(a, s);
-    if (a.nx == 3) return launch_qp_t<3>(a, s);
-    if (a.nx == 4) return launch_qp_t<4>(a, s);
-    set_error("nmpc_mpc_qp: no long-horizon kernel for nx=%d", a.nx);
-    return 1;
+    if (a.nx != 2) return launch_mpc_qp_wide_nx34(a, s);
+    const int kh = wide_kh(a.c.Nc, 2);
+    if (kh == 16) return launch_qp_wide_t<2, 16>(a, s);
+    if (kh == 25) return launch_qp_wide_t<2, 25>(a, s);
+    return launch_qp_wide_t<2, 32>(a, s);
 }
 
 int launch_mpc_solve_wide(const CtrlDev& d, const RunPtrs& rp, int it, int k, hipStream_t s) {
-    if (d.nx == 2) return launch_solve_t<2>(d, rp, it, k, s);
-    if (d.nx == 3) return launch_solve_t<3>(d, rp, it, k, s);
-    if (d.nx == 4) return launch_solve_t<4>(d, rp, it, k, s);
-    set_error("nmpc_ctrl_run: no long-horizon kernel for nx=%d", d.nx);
-    return 1;
+    if (d.nx != 2) return launch_mpc_solve_wide_nx34(d, rp, it, k, s);
+    const int kh = wide_kh(d.Nc, 2);
+    if (kh == 16) return launch_solve_wide_t<2, 16>(d, rp, it, k, s);
+    if (kh == 25) return launch_solve_wide_t<2, 25>(d, rp, it, k, s);
+    return launch_solve_wide_t<2, 32>(d, rp, it, k, s);
 }
 
 }  // namespace nmpc
