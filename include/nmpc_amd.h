@@ -46,6 +46,14 @@ int nmpc_version(void);
 int nmpc_model_create(nmpc_model** out, int nx, int nu, int ny, int hidden, int n_enc_in,
                       const float* const* fn_params, const float* const* hn_params,
                       const float* const* enc_params);
+/* Nets with another number of hidden layers (reference: mpcUtil.py:6-31 CasADiExp loops over
+ * f_n_hidden_layers; called from NMPC.py:517):  W_lin z + b_lin + W_out t_L + b_out,  t_l = tanh(W_l t_{l-1} + b_l),
+ * t_0 = z.  params = 4 + 2 L HOST pointers in CasADiExp's order: [0] W_lin [1] b_lin, then for hidden layer
+ * i = 0..L-1 [2+2i] W[hidden, in or hidden] [3+2i] b[hidden], then [2+2L] W_out[out,hidden] [3+2L] b_out.
+ * 1..4 hidden layers per net (more than two: hidden <= 128); the observer net, when given, has two. */
+int nmpc_model_create_layers(nmpc_model** out, int nx, int nu, int ny, int hidden, int f_hidden_layers,
+                             int h_hidden_layers, int n_enc_in, const float* const* fn_params,
+                             const float* const* hn_params, const float* const* enc_params);
 void nmpc_model_destroy(nmpc_model* m);
 
 /* ---- LPV embedding (reference: lpv_int.py:4-100 lpv_int / lpv_int_C / lambda_simpson /

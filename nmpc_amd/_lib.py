@@ -21,6 +21,10 @@ SIGNATURES = {
     "nmpc_model_create": (ctypes.c_int, [ctypes.POINTER(c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_float_p),
                                          ctypes.POINTER(c_float_p), ctypes.POINTER(c_float_p)]),
+    "nmpc_model_create_layers": (ctypes.c_int, [ctypes.POINTER(c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                ctypes.POINTER(c_float_p), ctypes.POINTER(c_float_p),
+                                                ctypes.POINTER(c_float_p)]),
     "nmpc_model_destroy": (None, [c_void_p]),
     "nmpc_lpv_embed": (ctypes.c_int, [c_void_p, ctypes.c_int, c_void_p, c_void_p, c_void_p, c_float_p, c_float_p,
                                       ctypes.c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -65,21 +65,23 @@ constexpr int PK_TAIL = PACK_FLOATS - PK_REC1;   // REC1 + REC2 + LIN + J0, cont
 // One net in the layout of the general-width embedding kernel (embed_wide.hip); hidden width padded
 // to 16*ht (ht = 4, 8, 16), outputs padded to nout_pad (1, 4, 8), inputs to 16; all fp32, device.
 struct WideNet {
-    const float* fwd;   // [ht][ht][64][4]  A-fragments of c2*W2:  W[16T + (l&15)][16S + 4(l>>4) + j]
-    const float* rev;   // [ht][ht][64][4]  A-fragments of W2^T
+    const float* fwd;   // [layers-1][ht][ht][64][4]  A-fragments of c2*W_l, l = 2..layers:  W[16T + (l&15)][16S + 4(l>>4) + j]
+    const float* rev;   // [layers-1][ht][ht][64][4]  A-fragments of W_l^T (times 4 for l > 2)
     const float* w0t;   // [ht][64][4]      A-fragments of W0^T:   W0[16T + 4(l>>4) + j][l&15]
     const float* w0;    // [H][16]          W0 rows
     const float* cb0;   // [H]  c2*b0
-    const float* cb2;   // [H]  c2*b2
-    const float* w4s;   // [nout_pad][H]    4*W4
+    const float* cb2;   // [layers-1][H]  c2*b_l of hidden layers l = 2..layers
+    const float* w4s;   // [nout_pad][H]    output matrix, times 4 when layers >= 2
     const float* lin;   // [nout_pad][16]   W_lin
     const float* j0;    // [nout_pad][16]   nonlinear-branch Jacobian at the origin (fp64-evaluated)
     int ht, nout_pad;
+    int layers;         // hidden layers (mpcUtil.py:7,18-25: CasADiExp loops over f_n_hidden_layers); 2 = embed_wide.hip, else embed_deep.hip
 };
 
 // Device-resident packed networks.
 struct ModelDev {
     int nx, nu, ny, hidden, n_enc_in;
+    int f_layers, h_layers;   // hidden layers of the f and h nets
     float* fpack;   // f-net, fp32 MFMA layout
     float* hpack;   // h-net, fp32 MFMA layout
     float* fpack_h2;   // f-net, split-fp16 MFMA layout (same offsets, fragment regions hold halves)

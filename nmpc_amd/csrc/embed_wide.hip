@@ -16,40 +16,13 @@
 #include "../../include/nmpc_amd.h"
 #include "common.h"
 #include "embed.h"
+#include "embed_wide.h"
 
 namespace nmpc {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-struct WideArgs {
-    WideNet net;
-    const float* pa;   // [rows, na]
-    const float* pb;   // [rows, nb] (may be null when nb = 0)
-    float* oa;         // [rows, nout, na]
-    float* ob;         // [rows, nout, nb]
-    int na, nb, nout;
-    int npts;
-    const int* count_dev;
-    const int* act;
-    int group;
-};
 
 // LDS (floats): G[4 HT][64] layer-1 slopes | CB0[H] | CB2[H] | W4S[NOUT][H] | ACC[4][NOUT][64][4]
 template <int HT, int NOUT>
 __host__ __device__ constexpr int wide_lds_floats() { return 4 * HT * 64 + 2 * 16 * HT + NOUT * 16 * HT + 4 * NOUT * 256; }
-
-// A-fragment loads go through buffer instructions: one SGPR descriptor per matrix, the lane's byte
-// offset in one VGPR and the fragment's (compile-time) offset in the scalar operand.  Flat global loads
-// would need a 64-bit VGPR address per fragment - 256 of them per matrix at hidden width 256.
-typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t frag_rsrc(const float* p, int nfloats) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, nfloats * 4, 0x00020000);
-}
-__device__ __forceinline__ f32x4 frag_load(__amdgpu_buffer_rsrc_t r, int lane_bytes, int frag) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_bytes, frag * 1024, 0));
-}
-
-__device__ __forceinline__ float sigm2(float a) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-a)); }
 
 template <int HT, int NOUT, bool LOOP>
 __global__ __launch_bounds__(256, 1) void embed_wide_kernel(WideArgs a, NodeTable nt) {
@@ -201,6 +174,7 @@ static int wide_launch_t(const WideArgs& a, const NodeTable& nt, int grid, hipSt
 }
 
 static int wide_launch_net(const WideNet& net, WideArgs a, const NodeTable& nt, hipStream_t s, bool loop) {
+    if (net.layers != 2) return deep_launch_net(net, a, nt, s, loop);
     a.net = net;
     const int grid = (a.npts + 15) / 16;
 #define NMPC_WIDE_CASE(HT_, NO_) if (net.ht == HT_ && net.nout_pad == NO_) return wide_launch_t<HT_, NO_>(a, nt, grid, s, loop);

@@ -134,79 +134,95 @@ static bool pack_net_h2(const float* const* p, int n_in, int n_out, std::vector<
     return ok;
 }
 
-// Layout of the general-width kernel (embed_wide.hip): see WideNet in common.h.  Appends the
+// Layout of the general-width kernels (embed_wide.hip, embed_deep.hip): see WideNet in common.h.  Appends the
 // net's arrays to `slab` (floats) and records the offsets in `off` (fwd, rev, w0t, w0, cb0, cb2, w4s,
 // lin, j0).  hidden is padded with zero units to 16*ht, outputs with zero rows to nout_pad.
-static void pack_wide(const float* const* p, int n_in, int n_out, int hidden, int ht, int nout_pad,
+// p = 4 + 2 L arrays in the reference's order (mpcUtil.py:18-29): linear skip, L hidden layers, output layer.
+static void pack_wide(const float* const* p, int L, int n_in, int n_out, int hidden, int ht, int nout_pad,
                       std::vector<float>& slab, size_t off[9]) {
-    const float *lin_w = p[0], *w0 = p[2], *b0 = p[3], *w2 = p[4], *b2 = p[5], *w4 = p[6];
+    const float *lin_w = p[0], *w0 = p[2], *b0 = p[3], *wout = p[2 + 2 * L];
     const double c2 = 2.0 * 1.4426950408889634074;
-    const int H = 16 * ht;
-    auto W2 = [&](int i, int k) { return (i < hidden && k < hidden) ? (double)w2[(size_t)i * hidden + k] : 0.0; };
+    const int H = 16 * ht, nm = L - 1;                 // nm square layers l = 2..L
     auto grab = [&](size_t nfl) { const size_t o = slab.size(); slab.resize(o + ((nfl + 3) & ~(size_t)3), 0.0f); return o; };
-    off[0] = grab((size_t)ht * ht * 256); off[1] = grab((size_t)ht * ht * 256); off[2] = grab((size_t)ht * 256);
-    off[3] = grab((size_t)H * 16); off[4] = grab(H); off[5] = grab(H); off[6] = grab((size_t)nout_pad * H);
+    off[0] = grab((size_t)nm * ht * ht * 256); off[1] = grab((size_t)nm * ht * ht * 256); off[2] = grab((size_t)ht * 256);
+    off[3] = grab((size_t)H * 16); off[4] = grab(H); off[5] = grab((size_t)(nm > 0 ? nm : 1) * H); off[6] = grab((size_t)nout_pad * H);
     off[7] = grab((size_t)nout_pad * 16); off[8] = grab((size_t)nout_pad * 16);
-    for (int T = 0; T < ht; ++T)
-        for (int S = 0; S < ht; ++S)
-            for (int l = 0; l < 64; ++l)
-                for (int j = 0; j < 4; ++j) {
-                    const size_t o = (((size_t)T * ht + S) * 64 + l) * 4 + j;
-                    const int r = 16 * T + (l & 15), c = 16 * S + 4 * (l >> 4) + j;
-                    slab[off[0] + o] = (float)(c2 * W2(r, c));
-                    slab[off[1] + o] = (float)W2(c, r);                 // W2^T[r][c]
-                }
+    for (int li = 0; li < nm; ++li) {
+        const float* w = p[4 + 2 * li];
+        const float* b = p[5 + 2 * li];
+        auto W = [&](int i, int k) { return (i < hidden && k < hidden) ? (double)w[(size_t)i * hidden + k] : 0.0; };
+        // the reverse sweep multiplies the product of layer l > 2 by (1 - t^2)/4 of the layer below
+        const double rs = li >= 1 ? 4.0 : 1.0;
+        for (int T = 0; T < ht; ++T)
+            for (int S = 0; S < ht; ++S)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 4; ++j) {
+                        const size_t o = ((((size_t)li * ht + T) * ht + S) * 64 + l) * 4 + j;
+                        const int r = 16 * T + (l & 15), c = 16 * S + 4 * (l >> 4) + j;
+                        slab[off[0] + o] = (float)(c2 * W(r, c));
+                        slab[off[1] + o] = (float)(rs * W(c, r));            // W^T[r][c]
+                    }
+        for (int k = 0; k < hidden; ++k) slab[off[5] + (size_t)li * H + k] = (float)(c2 * (double)b[k]);
+    }
     for (int T = 0; T < ht; ++T)
         for (int l = 0; l < 64; ++l)
             for (int j = 0; j < 4; ++j) {
                 const int k = 16 * T + 4 * (l >> 4) + j, jn = l & 15;
                 slab[off[2] + ((size_t)T * 64 + l) * 4 + j] = (k < hidden && jn < n_in) ? w0[(size_t)k * n_in + jn] : 0.0f;
             }
+    const float osc = L >= 2 ? 4.0f : 1.0f;
     for (int k = 0; k < hidden; ++k) {
         for (int j = 0; j < n_in; ++j) slab[off[3] + (size_t)k * 16 + j] = w0[(size_t)k * n_in + j];
         slab[off[4] + k] = (float)(c2 * (double)b0[k]);
-        slab[off[5] + k] = (float)(c2 * (double)b2[k]);
-        for (int c = 0; c < n_out; ++c) slab[off[6] + (size_t)c * H + k] = 4.0f * w4[(size_t)c * hidden + k];
+        for (int c = 0; c < n_out; ++c) slab[off[6] + (size_t)c * H + k] = osc * wout[(size_t)c * hidden + k];
     }
     for (int c = 0; c < n_out; ++c)
         for (int j = 0; j < n_in; ++j) slab[off[7] + (size_t)c * 16 + j] = lin_w[(size_t)c * n_in + j];
-    // nonlinear-branch Jacobian at the origin (fp64)
-    std::vector<double> t1(hidden), d2(hidden), v(hidden);
-    for (int k = 0; k < hidden; ++k) t1[k] = std::tanh((double)b0[k]);
-    for (int i = 0; i < hidden; ++i) {
-        double a = b2[i];
-        for (int k = 0; k < hidden; ++k) a += (double)w2[(size_t)i * hidden + k] * t1[k];
-        const double t = std::tanh(a);
-        d2[i] = 1.0 - t * t;
+    // nonlinear-branch Jacobian at the origin (fp64): W_out D_L W_L ... D_1 W_0
+    std::vector<double> t(hidden), tn(hidden), M((size_t)hidden * n_in), Mn((size_t)hidden * n_in);
+    for (int k = 0; k < hidden; ++k) {
+        t[k] = std::tanh((double)b0[k]);
+        for (int j = 0; j < n_in; ++j) M[(size_t)k * n_in + j] = (1.0 - t[k] * t[k]) * (double)w0[(size_t)k * n_in + j];
     }
-    for (int c = 0; c < n_out; ++c) {
-        for (int k = 0; k < hidden; ++k) {
-            double a = 0.0;
-            for (int i = 0; i < hidden; ++i) a += (double)w4[(size_t)c * hidden + i] * d2[i] * (double)w2[(size_t)i * hidden + k];
-            v[k] = a * (1.0 - t1[k] * t1[k]);
+    for (int li = 0; li < nm; ++li) {
+        const float* w = p[4 + 2 * li];
+        const float* b = p[5 + 2 * li];
+        for (int i = 0; i < hidden; ++i) {
+            double a = b[i];
+            for (int k = 0; k < hidden; ++k) a += (double)w[(size_t)i * hidden + k] * t[k];
+            tn[i] = std::tanh(a);
+            for (int j = 0; j < n_in; ++j) {
+                double m = 0.0;
+                for (int k = 0; k < hidden; ++k) m += (double)w[(size_t)i * hidden + k] * M[(size_t)k * n_in + j];
+                Mn[(size_t)i * n_in + j] = (1.0 - tn[i] * tn[i]) * m;
+            }
         }
+        t = tn; M = Mn;
+    }
+    for (int c = 0; c < n_out; ++c)
         for (int j = 0; j < n_in; ++j) {
             double a = 0.0;
-            for (int k = 0; k < hidden; ++k) a += v[k] * (double)w0[(size_t)k * n_in + j];
+            for (int k = 0; k < hidden; ++k) a += (double)wout[(size_t)c * hidden + k] * M[(size_t)k * n_in + j];
             slab[off[8] + (size_t)c * 16 + j] = (float)a;
         }
-    }
 }
 
-static void eval_net_at_zero(const float* const* p, int n_in, int n_out, int hidden, double* y) {
-    std::vector<double> t1(hidden), t2(hidden);
-    for (int k = 0; k < hidden; ++k) t1[k] = std::tanh((double)p[3][k]);
-    for (int i = 0; i < hidden; ++i) {
-        double a = p[5][i];
-        for (int k = 0; k < hidden; ++k) a += (double)p[4][i * hidden + k] * t1[k];
-        t2[i] = std::tanh(a);
+static void eval_net_at_zero(const float* const* p, int L, int n_out, int hidden, double* y) {
+    std::vector<double> t(hidden), tn(hidden);
+    for (int k = 0; k < hidden; ++k) t[k] = std::tanh((double)p[3][k]);
+    for (int li = 0; li + 1 < L; ++li) {
+        for (int i = 0; i < hidden; ++i) {
+            double a = p[5 + 2 * li][i];
+            for (int k = 0; k < hidden; ++k) a += (double)p[4 + 2 * li][(size_t)i * hidden + k] * t[k];
+            tn[i] = std::tanh(a);
+        }
+        t = tn;
     }
     for (int c = 0; c < n_out; ++c) {
-        double a = (double)p[1][c] + (double)p[7][c];
-        for (int k = 0; k < hidden; ++k) a += (double)p[6][c * hidden + k] * t2[k];
+        double a = (double)p[1][c] + (double)p[3 + 2 * L][c];
+        for (int k = 0; k < hidden; ++k) a += (double)p[2 + 2 * L][(size_t)c * hidden + k] * t[k];
         y[c] = a;
     }
-    (void)n_in;
 }
 
 }  // namespace nmpc
@@ -217,11 +233,12 @@ extern "C" const char* nmpc_last_error(void) { return g_err.c_str(); }
 extern "C" int nmpc_version(void) { return 100; }
 
 // Packs and uploads the nets into `m` (zero-initialised); on failure the caller destroys `m`.
-static int model_fill(nmpc_model* m, int nx, int nu, int ny, int hidden, int n_enc_in, const float* const* fn,
-                      const float* const* hn, const float* const* enc) {
+static int model_fill(nmpc_model* m, int nx, int nu, int ny, int hidden, int Lf, int Lh, int n_enc_in,
+                      const float* const* fn, const float* const* hn, const float* const* enc) {
     // the 64-wide kernels (embed.hip) are instantiated for these sizes; everything else runs on the
     // general-width kernel (embed_wide.hip)
-    const bool narrow = hidden == HID && nu == 1 && ny == 1 && (nx == 2 || nx == 3);
+    const bool narrow = hidden == HID && nu == 1 && ny == 1 && (nx == 2 || nx == 3) && Lf == 2 && Lh == 2;
+    m->d.f_layers = Lf; m->d.h_layers = Lh;
     m->d.nx = nx; m->d.nu = nu; m->d.ny = ny; m->d.hidden = hidden; m->d.n_enc_in = enc ? n_enc_in : 0;
     NMPC_HIP_CHECK(hipGetDevice(&m->device));
     m->d.narrow_ok = narrow ? 1 : 0;
@@ -238,21 +255,21 @@ static int model_fill(nmpc_model* m, int nx, int nu, int ny, int hidden, int n_e
         auto padout = [](int n) { return n <= 1 ? 1 : (n <= 4 ? 4 : 8); };
         std::vector<float> slab;
         size_t of[9], oh[9];
-        pack_wide(fn, nx + nu, nx, hidden, ht, padout(nx), slab, of);
-        pack_wide(hn, nx, ny, hidden, ht, padout(ny), slab, oh);
+        pack_wide(fn, Lf, nx + nu, nx, hidden, ht, padout(nx), slab, of);
+        pack_wide(hn, Lh, nx, ny, hidden, ht, padout(ny), slab, oh);
         NMPC_HIP_CHECK(hipMalloc(&m->d.wide_slab, slab.size() * sizeof(float)));
         NMPC_HIP_CHECK(hipMemcpy(m->d.wide_slab, slab.data(), slab.size() * sizeof(float), hipMemcpyHostToDevice));
-        auto bind = [&](WideNet& w, const size_t* o, int nout_pad) {
+        auto bind = [&](WideNet& w, const size_t* o, int nout_pad, int layers) {
             const float* b = m->d.wide_slab;
             w.fwd = b + o[0]; w.rev = b + o[1]; w.w0t = b + o[2]; w.w0 = b + o[3]; w.cb0 = b + o[4]; w.cb2 = b + o[5];
-            w.w4s = b + o[6]; w.lin = b + o[7]; w.j0 = b + o[8]; w.ht = ht; w.nout_pad = nout_pad;
+            w.w4s = b + o[6]; w.lin = b + o[7]; w.j0 = b + o[8]; w.ht = ht; w.nout_pad = nout_pad; w.layers = layers;
         };
-        bind(m->d.wide_f, of, padout(nx)); bind(m->d.wide_h, oh, padout(ny));
+        bind(m->d.wide_f, of, padout(nx), Lf); bind(m->d.wide_h, oh, padout(ny), Lh);
     }
-    eval_net_at_zero(fn, nx + nu, nx, hidden, m->d.f0);
-    eval_net_at_zero(hn, nx, ny, hidden, m->d.h0);
+    eval_net_at_zero(fn, Lf, nx, hidden, m->d.f0);
+    eval_net_at_zero(hn, Lh, ny, hidden, m->d.h0);
     // plain-layout nets for the closed loop's observer / output step (one hidden unit per lane)
-    const bool loop_ok = hidden == HID && nu == 1 && ny == 1 && nx >= 2 && nx <= 4;
+    const bool loop_ok = hidden == HID && nu == 1 && ny == 1 && nx >= 2 && nx <= 4 && Lf == 2 && Lh == 2;
     auto upload_plain = [&](const float* const* p, int n_in, int n_out, float** dst) -> int {
         const int sz[8] = {n_out * n_in, n_out, hidden * n_in, hidden, hidden * hidden, hidden, n_out * hidden, n_out};
         std::vector<float> e;
@@ -263,7 +280,7 @@ static int model_fill(nmpc_model* m, int nx, int nu, int ny, int hidden, int n_e
         NMPC_HIP_CHECK(hipMemcpy(*dst, e.data(), e.size() * sizeof(float), hipMemcpyHostToDevice));
         return 0;
     };
-    NMPC_REQUIRE(!enc || loop_ok, "nmpc_model_create: an observer net needs hidden = 64, nu = ny = 1, nx = 2..4");
+    NMPC_REQUIRE(!enc || loop_ok, "nmpc_model_create: an observer net needs hidden = 64, two hidden layers, nu = ny = 1, nx = 2..4");
     if (loop_ok) {
         if (upload_plain(hn, nx, ny, &m->d.hplain)) return 1;
         if (enc && upload_plain(enc, n_enc_in, nx, &m->d.enc)) return 1;
@@ -289,23 +306,33 @@ static int model_fill(nmpc_model* m, int nx, int nu, int ny, int hidden, int n_e
     return 0;
 }
 
-extern "C" int nmpc_model_create(nmpc_model** out, int nx, int nu, int ny, int hidden, int n_enc_in,
-                                 const float* const* fn, const float* const* hn,
-                                 const float* const* enc) {
+extern "C" int nmpc_model_create_layers(nmpc_model** out, int nx, int nu, int ny, int hidden, int f_hidden_layers,
+                                        int h_hidden_layers, int n_enc_in, const float* const* fn,
+                                        const float* const* hn, const float* const* enc) {
     NMPC_REQUIRE(out && fn && hn, "nmpc_model_create: null argument");
     NMPC_REQUIRE(hidden >= 1 && hidden <= 256, "nmpc_model_create: hidden width %d unsupported (1..256)", hidden);
+    NMPC_REQUIRE(f_hidden_layers >= 1 && f_hidden_layers <= 4 && h_hidden_layers >= 1 && h_hidden_layers <= 4,
+                 "nmpc_model_create: hidden layer counts %d / %d unsupported (1..4)", f_hidden_layers, h_hidden_layers);
+    NMPC_REQUIRE(hidden <= 128 || (f_hidden_layers <= 2 && h_hidden_layers <= 2),
+                 "nmpc_model_create: more than two hidden layers need hidden <= 128 (got %d)", hidden);
     NMPC_REQUIRE(nx >= 1 && nu >= 1 && ny >= 1 && nx <= 8 && nx + nu <= 16 && ny <= 8,
                  "nmpc_model_create: dims nx=%d nu=%d ny=%d unsupported (need nx<=8, nx+nu<=16, ny<=8)", nx, nu, ny);
     NMPC_REQUIRE(!enc || (n_enc_in >= 1 && n_enc_in <= 32), "nmpc_model_create: bad encoder input size %d",
                  n_enc_in);
     nmpc_model* m = new nmpc_model();
     std::memset(m, 0, sizeof(*m));
-    if (model_fill(m, nx, nu, ny, hidden, n_enc_in, fn, hn, enc)) {
+    if (model_fill(m, nx, nu, ny, hidden, f_hidden_layers, h_hidden_layers, n_enc_in, fn, hn, enc)) {
         nmpc_model_destroy(m);          // frees whatever was uploaded before the failure
         return 1;
     }
     *out = m;
     return 0;
+}
+
+extern "C" int nmpc_model_create(nmpc_model** out, int nx, int nu, int ny, int hidden, int n_enc_in,
+                                 const float* const* fn, const float* const* hn,
+                                 const float* const* enc) {
+    return nmpc_model_create_layers(out, nx, nu, ny, hidden, 2, 2, n_enc_in, fn, hn, enc);
 }
 
 extern "C" void nmpc_model_destroy(nmpc_model* m) {

@@ -26,8 +26,10 @@ class Norm:
 
 
 class Encoder:
-    """fn / hn / encoder nets on the device.  `params` maps net name -> 8 fp32 arrays in the
-    reference's parameter order (mpcUtil.py:18-29)."""
+    """fn / hn / encoder nets on the device.  `params` maps net name -> 4 + 2 L fp32 arrays in the
+    reference's parameter order (mpcUtil.py:18-29): linear skip weight and bias, weight and bias of each of
+    the L hidden layers, output weight and bias (L = 2 for the trained disc model; CasADiExp,
+    mpcUtil.py:6-31, takes L from the model's f_n_hidden_layers)."""
 
     def __init__(self, params, norm=None, na=4, nb=4, device=None):
         import torch
@@ -37,7 +39,12 @@ class Encoder:
         self.hidden = fn[2].shape[0]
         self.nx = hn[2].shape[1]
         self.nu = fn[2].shape[1] - self.nx
-        self.ny = hn[6].shape[0]
+        self.ny = hn[-2].shape[0]
+        for name, lst in self.params.items():
+            if len(lst) < 6 or len(lst) % 2:
+                raise _lib.NmpcError("net %r: expected 4 + 2 L parameter arrays, got %d" % (name, len(lst)))
+        self.f_n_hidden_layers = (len(fn) - 4) // 2
+        self.h_n_hidden_layers = (len(hn) - 4) // 2
         self.na, self.nb = int(na), int(nb)
         self.norm = norm or Norm()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -45,15 +52,18 @@ class Encoder:
         self.n_enc_in = enc[2].shape[1] if enc is not None else 0
 
         def parr(lst):
-            arr = (_lib.c_float_p * 8)()
+            arr = (_lib.c_float_p * len(lst))()
             for i, a in enumerate(lst):
                 arr[i] = a.ctypes.data_as(_lib.c_float_p)
             return arr
         h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
-            rc = _lib.lib().nmpc_model_create(ctypes.byref(h), self.nx, self.nu, self.ny, self.hidden, self.n_enc_in,
-                                              parr(fn), parr(hn), parr(enc) if enc is not None else None)
-        _lib.check(rc, "nmpc_model_create")
+            if enc is not None and len(enc) != 8:
+                raise _lib.NmpcError("the observer net must have two hidden layers (8 parameter arrays)")
+            rc = _lib.lib().nmpc_model_create_layers(ctypes.byref(h), self.nx, self.nu, self.ny, self.hidden,
+                                                     self.f_n_hidden_layers, self.h_n_hidden_layers, self.n_enc_in,
+                                                     parr(fn), parr(hn), parr(enc) if enc is not None else None)
+        _lib.check(rc, "nmpc_model_create_layers")
         self.handle = h
 
     def __del__(self):
@@ -67,9 +77,13 @@ class Encoder:
 
     @staticmethod
     def _net_at_zero(p):
-        """W_lin 0 + b_lin + W4 tanh(W2 tanh(b0) + b2) + b4 in fp64 (host; a constant of the model)."""
-        lin_w, lin_b, w0, b0, w2, b2, w4, b4 = [np.asarray(a, np.float64) for a in p]
-        return lin_b + w4 @ np.tanh(w2 @ np.tanh(b0) + b2) + b4
+        """The net at z = 0 in fp64 (host; a constant of the model): b_lin + W_out t_L + b_out with
+        t_1 = tanh(b_0), t_l = tanh(W_l t_{l-1} + b_l)."""
+        p = [np.asarray(a, np.float64) for a in p]
+        t = np.tanh(p[3])
+        for i in range(4, len(p) - 2, 2):
+            t = np.tanh(p[i] @ t + p[i + 1])
+        return p[1] + p[-2] @ t + p[-1]
 
     @property
     def f0(self):

@@ -3,6 +3,8 @@ net and their Jacobians.
 
 Network structure (deepSI simple_res_net, as re-expressed by mpcUtil.py:6-82 of the
 reference):   net(z) = W_lin z + b_lin + W4 tanh(W2 tanh(W0 z + b0) + b2) + b4
+(two hidden layers: CasADiFn / CasADiHn, mpcUtil.py:34,58; CasADiExp, mpcUtil.py:6-31, loops over the
+model's f_n_hidden_layers, which ResNet follows for any count)
 with z = [x; u] for f (mpcUtil.py:66), z = x for h (mpcUtil.py:41) and
 z = [u_hist; y_hist] for the encoder (deepSI encoders.py forward, traceback in
 Observer.ipynb cell 14).
@@ -21,36 +23,50 @@ DEFAULT_WEIGHTS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..",
 
 
 class ResNet:
-    """Linear skip + 2-hidden-layer tanh MLP, evaluated in fp64 on arrays [..., n_in]."""
+    """Linear skip + tanh MLP with L hidden layers (L = 2 for the trained model; mpcUtil.py:6-31 CasADiExp takes
+    L from the model), evaluated in fp64 on arrays [..., n_in].  Arguments in the reference's parameter order:
+    lin_w, lin_b, then (W, b) of each hidden layer, then (W, b) of the output layer."""
 
-    def __init__(self, lin_w, lin_b, w0, b0, w2, b2, w4, b4):
+    def __init__(self, lin_w, lin_b, *rest):
         f = lambda a: np.asarray(a, dtype=np.float64)
+        assert len(rest) >= 4 and len(rest) % 2 == 0
         self.lin_w, self.lin_b = f(lin_w), f(lin_b)
-        self.w0, self.b0, self.w2, self.b2, self.w4, self.b4 = f(w0), f(b0), f(w2), f(b2), f(w4), f(b4)
-        self.n_in = self.w0.shape[1]
-        self.n_out = self.w4.shape[0]
-        self.hidden = self.w0.shape[0]
+        self.hid = [[f(rest[i]), f(rest[i + 1])] for i in range(0, len(rest) - 2, 2)]
+        self.out = [f(rest[-2]), f(rest[-1])]
+        self.n_in = self.hid[0][0].shape[1]
+        self.n_out = self.out[0].shape[0]
+        self.hidden = self.hid[0][0].shape[0]
+        self.n_hidden_layers = len(self.hid)
+
+    # names of the two-hidden-layer case (net_non_lin.net.{0,2,4} of the model file)
+    w0 = property(lambda s: s.hid[0][0], lambda s, v: s.hid[0].__setitem__(0, v))
+    b0 = property(lambda s: s.hid[0][1], lambda s, v: s.hid[0].__setitem__(1, v))
+    w2 = property(lambda s: s.hid[1][0], lambda s, v: s.hid[1].__setitem__(0, v))
+    b2 = property(lambda s: s.hid[1][1], lambda s, v: s.hid[1].__setitem__(1, v))
+    w4 = property(lambda s: s.out[0], lambda s, v: s.out.__setitem__(0, v))
+    b4 = property(lambda s: s.out[1], lambda s, v: s.out.__setitem__(1, v))
 
     def params(self):
-        return [getattr(self, n) for n in _NAMES]
+        return [self.lin_w, self.lin_b] + [a for wb in self.hid for a in wb] + list(self.out)
 
     def __call__(self, z):
         z = np.asarray(z, dtype=np.float64)
-        t1 = np.tanh(z @ self.w0.T + self.b0)
-        t2 = np.tanh(t1 @ self.w2.T + self.b2)
-        return z @ self.lin_w.T + self.lin_b + t2 @ self.w4.T + self.b4
+        t = z
+        for w, b in self.hid:
+            t = np.tanh(t @ w.T + b)
+        return z @ self.lin_w.T + self.lin_b + t @ self.out[0].T + self.out[1]
 
     def jac(self, z):
-        """dnet/dz at z[..., n_in] -> [..., n_out, n_in]."""
+        """dnet/dz at z[..., n_in] -> [..., n_out, n_in]:  W_lin + W_out D_L W_L ... D_1 W_0."""
         z = np.asarray(z, dtype=np.float64)
-        t1 = np.tanh(z @ self.w0.T + self.b0)
-        t2 = np.tanh(t1 @ self.w2.T + self.b2)
-        d1 = 1.0 - t1 * t1
-        d2 = 1.0 - t2 * t2
-        # (W4 diag d2) (W2 diag d1) W0, batched over leading dims
-        m2 = self.w4[None, :, :] * d2.reshape(-1, 1, self.hidden)          # [P, out, H]
-        m1 = self.w2[None, :, :] * d1.reshape(-1, 1, self.hidden)          # [P, H, H]
-        j = m2 @ m1 @ self.w0 + self.lin_w
+        zf = z.reshape(-1, self.n_in)
+        t = zf
+        m = None                                             # [P, H, n_in]: d t_l / d z
+        for w, b in self.hid:
+            t = np.tanh(t @ w.T + b)
+            wm = w[None, :, :] if m is None else w[None, :, :] @ m
+            m = (1.0 - t * t)[:, :, None] * wm
+        j = self.out[0][None, :, :] @ m + self.lin_w
         return j.reshape(z.shape[:-1] + (self.n_out, self.n_in))
 
 
@@ -78,16 +94,19 @@ class Model:
                    d["na"], d["nb"])
 
     @classmethod
-    def synthetic(cls, nx, nu, ny, hidden, seed=0, n_hist=9):
-        """Random nets with weights N(0, 1/fan_in); used for the wide-model configuration."""
+    def synthetic(cls, nx, nu, ny, hidden, seed=0, n_hist=9, f_layers=2, h_layers=2):
+        """Random nets with weights N(0, 1/fan_in); used for the wide-model configuration.  f_layers / h_layers:
+        hidden layers of the f and h nets (the observer net keeps two)."""
         rng = np.random.default_rng(seed)
 
-        def net(n_in, n_out):
+        def net(n_in, n_out, layers=2):
             g = lambda r, c: (rng.standard_normal((r, c)) / np.sqrt(c)).astype(np.float32)
             b = lambda r: (0.1 * rng.standard_normal(r)).astype(np.float32)
-            return ResNet(g(n_out, n_in), b(n_out), g(hidden, n_in), b(hidden),
-                          g(hidden, hidden), b(hidden), g(n_out, hidden), b(n_out))
-        return cls(net(nx + nu, nx), net(nx, ny), net(n_hist, nx))
+            p = [g(n_out, n_in), b(n_out), g(hidden, n_in), b(hidden)]
+            for _ in range(layers - 1):
+                p += [g(hidden, hidden), b(hidden)]
+            return ResNet(*(p + [g(n_out, hidden), b(n_out)]))
+        return cls(net(nx + nu, nx, f_layers), net(nx, ny, h_layers), net(n_hist, nx))
 
     # --- model functions -------------------------------------------------------------
     def f(self, x, u):

@@ -248,6 +248,47 @@ def test_wide_nets(nx, nu, ny, H):
         nmpc_amd.Controller(enc, nmpc_amd.OutputUnbalancedDisc(dt=0.1), 4, 10, 5, 4, np.eye(nx), 1.0, -1, 1, -1, 1, lam, w)
 
 
+@pytest.mark.parametrize("nx,nu,ny,H,Lf,Lh", [(2, 1, 1, 64, 1, 1), (2, 1, 1, 64, 3, 3), (4, 1, 1, 64, 4, 4), (3, 2, 2, 128, 1, 3),
+                                               (8, 1, 3, 128, 3, 1), (5, 1, 2, 100, 3, 2), (2, 1, 1, 256, 1, 2)])
+def test_hidden_layer_counts(nx, nu, ny, H, Lf, Lh):
+    """Nets with 1, 3 or 4 hidden layers, as CasADiExp (mpcUtil.py:6-31, used by par_NMPC_linear at NMPC.py:517)
+    accepts them through f_n_hidden_layers: parameters in its order, embedding against the fp64 oracle at the same
+    bar as the two-layer nets, f(0,0) / h(0) against the oracle."""
+    import nmpc_amd
+    from oracle.model import Model
+    om = Model.synthetic(nx, nu, ny, H, seed=7, f_layers=Lf, h_layers=Lh)
+    params = {k: [np.asarray(a, np.float32) for a in n.params()] for k, n in (("fn", om.fn), ("hn", om.hn))}
+    assert len(params["fn"]) == 4 + 2 * Lf and len(params["hn"]) == 4 + 2 * Lh
+    enc = nmpc_amd.Encoder(params, device="cuda:0")
+    assert enc.f_n_hidden_layers == Lf and enc.h_n_hidden_layers == Lh
+    assert np.abs(enc.f0 - om.f0).max() < 1e-12 and np.abs(enc.h0 - om.h0).max() < 1e-12
+    rng = np.random.default_rng(9)
+    for P, stages in ((1, 10), (53, 20)):
+        x = f32(rng.uniform(-2, 2, (P, nx))); u = f32(rng.uniform(-2, 2, (P, nu))); xc = f32(rng.uniform(-2, 2, (P, nx)))
+        lam, w = nmpc_amd.quad_nodes("simpson", stages)
+        A, B, C = nmpc_amd.embed(enc, torch.tensor(x), torch.tensor(u), torch.tensor(xc), lam, w)
+        Ao, Bo, Co = olpv.embed(om, x, u, *olpv.merge_nodes(*olpv.quad_nodes("simpson", stages)), xc=xc)
+        for got, ref in ((A, Ao), (B, Bo), (C, Co)):
+            err = np.abs(got.cpu().numpy().astype(np.float64).reshape(ref.shape) - ref).max()
+            assert err / np.abs(ref).max() < TOL
+    A2, B2, C2 = nmpc_amd.embed(enc, torch.tensor(x), torch.tensor(u), torch.tensor(xc), lam, w)
+    assert torch.equal(A, A2) and torch.equal(B, B2) and torch.equal(C, C2)
+
+
+def test_hidden_layer_limits():
+    """More than two hidden layers of more than 128 units do not fit the kernel's LDS plan: refused at creation."""
+    import nmpc_amd
+    from oracle.model import Model
+    om = Model.synthetic(2, 1, 1, 256, seed=1, f_layers=3, h_layers=2)
+    params = {k: [np.asarray(a, np.float32) for a in n.params()] for k, n in (("fn", om.fn), ("hn", om.hn))}
+    with pytest.raises(nmpc_amd.NmpcError):
+        nmpc_amd.Encoder(params, device="cuda:0")
+    om = Model.synthetic(2, 1, 1, 32, seed=1, f_layers=5, h_layers=2)
+    params = {k: [np.asarray(a, np.float32) for a in n.params()] for k, n in (("fn", om.fn), ("hn", om.hn))}
+    with pytest.raises(nmpc_amd.NmpcError):
+        nmpc_amd.Encoder(params, device="cuda:0")
+
+
 def test_wide_kernel_on_the_disc_model(enc, omodel, monkeypatch):
     """The general-width kernel is a drop-in for the 64-wide one: same model, same bar."""
     import subprocess, sys, os

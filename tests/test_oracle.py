@@ -67,6 +67,31 @@ def test_jacobian_golden(golden, omodel):
     assert np.abs(omodel.Jhx(j["x"]) - j["Jhx"]).max() < 1e-11
 
 
+@pytest.mark.parametrize("layers", [1, 2, 3, 4])
+def test_jacobian_of_nets_with_other_layer_counts(layers):
+    """CasADiExp (mpcUtil.py:6-31) re-expresses a net with any number of hidden layers in the parameter order
+    lin, hidden 0..L-1, output; the reference takes its Jacobian by automatic differentiation
+    (casadi.jacobian, NMPC.py:530-531; vmap(jacrev), NMPC_test.py:137-138).  The oracle's closed form is
+    checked against torch.func.vmap(jacrev) of the same expression."""
+    import torch
+    from oracle.model import Model
+    om = Model.synthetic(3, 2, 2, 24, seed=11, f_layers=layers, h_layers=layers)
+    rng = np.random.default_rng(5)
+    for net, n_in in ((om.fn, 5), (om.hn, 3)):
+        assert net.n_hidden_layers == layers and len(net.params()) == 4 + 2 * layers
+        pl = [torch.tensor(a) for a in net.params()]
+
+        def expr(z):                       # the loop of mpcUtil.py:17-31
+            t = z
+            for i in range(layers):
+                t = torch.tanh(pl[2 + 2 * i] @ t + pl[3 + 2 * i])
+            return pl[2 + 2 * layers] @ t + pl[3 + 2 * layers] + pl[0] @ z + pl[1]
+        z = rng.uniform(-2, 2, (40, n_in))
+        want = torch.func.vmap(torch.func.jacrev(expr))(torch.tensor(z)).numpy()
+        assert np.abs(net.jac(z) - want).max() < 1e-12
+        assert np.abs(net(z) - torch.func.vmap(expr)(torch.tensor(z)).numpy()).max() < 1e-12
+
+
 def test_quadrature_golden(golden, omodel):
     l = golden["lpv"]
     x, u = l["x"], l["u"]
