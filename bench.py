@@ -252,6 +252,10 @@ def closed_loop_bench(args, cfgname, rank, world, dev, shard):
     torch.cuda.synchronize(dev)
     t_targets = time.perf_counter() - t0
     plant = nmpc_amd.OutputUnbalancedDisc(dt=0.1, sigma_n=[cfg["sigma"]])
+    stamps = None
+    if args.solve_stamps:          # diagnostics: per-phase clock stamps of every controller's last condense+QP solve
+        stamps = torch.zeros(B, 16, dtype=torch.int64, device=dev)
+        os.environ["NMPC_MPC_STAMPS"] = hex(stamps.data_ptr())
     ctrl = nmpc_amd.Controller(enc, plant, B, NC, nsim, cfg["max_it"], np.diag([1000.0, 10.0]), 1.0, umin_n, umax_n,
                                ymin_n, ymax_n, lam, w, tol=cfg["tol"], rho=1000.0)
     noise = None
@@ -288,6 +292,21 @@ def closed_loop_bench(args, cfgname, rank, world, dev, shard):
         torch.cuda.synchronize(dev)
         lat.append(time.perf_counter() - t1)
     p50_latency = float(np.median(lat)) * 1e3 if lat else None
+    if stamps is not None and rank == 0:
+        st = stamps.cpu().numpy().astype(np.float64)
+        st = st[st[:, 13] > 0]
+        names = ["recurrences", "qd", "hessian/rows", "cholesky", "transform", "slack init", "warm start", "active-set loop", "recover z",
+                 "predict"]
+        seq = np.stack([st[:, 0], st[:, 1], st[:, 2], st[:, 3], st[:, 4], st[:, 5], st[:, 6], st[:, 15], st[:, 7], st[:, 8], st[:, 9]], 1)
+        d = np.diff(seq, axis=1)
+        sys.stderr.write("solve stamps (%d controllers, last solve each; shader clock cycles): median / mean / max\n" % len(st))
+        sys.stderr.write("  %-16s %8.0f %8.0f %8.0f\n" % ("prologue", np.median(st[:, 0] - st[:, 12]), (st[:, 0] - st[:, 12]).mean(), (st[:, 0] - st[:, 12]).max()))
+        for i, nm_ in enumerate(names):
+            sys.stderr.write("  %-16s %8.0f %8.0f %8.0f\n" % (nm_, np.median(d[:, i]), d[:, i].mean(), d[:, i].max()))
+        sys.stderr.write("  %-16s %8.0f %8.0f %8.0f\n" % ("epilogue", np.median(st[:, 13] - st[:, 9]), (st[:, 13] - st[:, 9]).mean(), (st[:, 13] - st[:, 9]).max()))
+        tot_c = st[:, 13] - st[:, 12]
+        sys.stderr.write("  %-16s %8.0f %8.0f %8.0f   iterations mean %.2f; clock %.2f GHz\n" % ("kernel", np.median(tot_c), tot_c.mean(), tot_c.max(), st[:, 10].mean(),
+                         np.median((st[:, 9] - st[:, 0]) / np.maximum(st[:, 11], 1)) * 0.1))
     qp_fail, qp_solves, qp_iters = ctrl.stats()
     if qp_fail:
         raise SystemExit("QP failures in the closed loop: result invalid")
@@ -485,6 +504,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=12, help="steps per controller of the 1-thread slice baseline")
     ap.add_argument("--cpu-steps-mt", type=int, default=120, help="steps per controller of the all-threads slice baseline")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--solve-stamps", action="store_true", help="diagnostics: per-phase clock stamps of the long-horizon solve kernel (stderr)")
     ap.add_argument("--latency-steps", type=int, default=40,
                     help="single steps run after the timed regions for p50_step_latency_ms (0: skip)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",

@@ -213,6 +213,7 @@ __global__ void reset_kernel(CtrlDev d, double u0n, double x0a, double x0b, doub
     for (int i = 0; i < Nc; ++i) { d.uplan[(size_t)b * Nc + i] = u0n; d.us32[(size_t)b * Nc + i] = (float)u0n; }
     d.ymeas[b] = 0.0; d.eps[b] = 0.0; d.cnt[b] = 0;
     d.qp_stat[2 * b] = 0u; d.qp_stat[2 * b + 1] = 0u;
+    if (d.wcnt) d.wcnt[b] = 0;
     d.xp[2 * b] = pw; d.xp[2 * b + 1] = pth;
     for (int j = 0; j < d.na; ++j) d.uhist[(size_t)b * d.na + j] = 0.0;
     for (int j = 0; j < d.nyh; ++j) d.yhist[(size_t)b * d.nyh + j] = 0.0;
@@ -290,13 +291,13 @@ extern "C" int nmpc_mpc_qp(int nb, int Nc, int nx, const double* list_A, const d
     a.nb = nb; a.nx = nx; a.lA = list_A; a.lB = list_B; a.lC = list_C; a.x0 = x0; a.ymeas = y_meas; a.Xs = Xs; a.Us = Us;
     a.Ge = Ge; a.Fe = Fe; a.Le = Le; a.hv = hv; a.u = u; a.eps = eps; a.xpred = xpred; a.status = status;
     fill_const(a.c, Nc, nx, Q, R, rho, u_min, u_max, y_min, y_max, f0, h0);
-    // diagnostics: NMPC_MPC_STAMPS=<device pointer, hex> receives 12 clock stamps per problem
+    // diagnostics: NMPC_MPC_STAMPS=<device pointer, hex> receives 16 clock stamps per problem
     if (const char* e = getenv("NMPC_MPC_STAMPS")) {
         void* p = (void*)strtoull(e, nullptr, 16);
         hipPointerAttribute_t at;
         NMPC_REQUIRE(p && hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeDevice,
                      "nmpc_mpc_qp: NMPC_MPC_STAMPS does not name device memory");
-        a.stamps = (unsigned long long*)p;       // the caller provides 12 * nb words
+        a.stamps = (unsigned long long*)p;       // the caller provides 16 * nb words
     }
     return dispatch_mpc_qp(a, g, (hipStream_t)stream);
 }
@@ -405,6 +406,17 @@ extern "C" int nmpc_ctrl_create(nmpc_ctrl** out, const nmpc_model* m, const nmpc
     rc |= alloc((void**)&d.xs32, sb * Nc * nx * 4); rc |= alloc((void**)&d.us32, sb * Nc * 4);
     rc |= alloc((void**)&d.xc32, sb * Nc * nx * 4); rc |= alloc((void**)&d.A32, sb * Nc * nx * nx * 4);
     rc |= alloc((void**)&d.B32, sb * Nc * nx * 4); rc |= alloc((void**)&d.C32, sb * Nc * nx * 4);
+    if (mpc_wide_applies(Nc, nx, d.c.mode, d.c.slack)) {
+        // long-horizon kernels carry each controller's working set from one QP solve to the next
+        rc |= alloc((void**)&d.wset, sb * 64); rc |= alloc((void**)&d.wcnt, sb * 4);
+        const char* e = getenv("NMPC_QP_WARM");
+        d.warm = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    if (const char* e = getenv("NMPC_MPC_STAMPS")) {      // diagnostics: 16 clock stamps per controller (device memory)
+        void* p = (void*)strtoull(e, nullptr, 16);
+        hipPointerAttribute_t at;
+        if (p && hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeDevice) d.stamps = (unsigned long long*)p;
+    }
     if (rc) { nmpc_ctrl_destroy(c); return 1; }
     // slices: NMPC_CTRL_SLICES (1..8) overrides the default (3 from 1536 controllers, 2 from 1024, else 1;
     // three slice streams and the caller's stream fill the four hardware queues of a process)
@@ -425,6 +437,8 @@ extern "C" int nmpc_ctrl_create(nmpc_ctrl** out, const nmpc_model* m, const nmpc
         sl.d.act += o * (d.maxit + 1); sl.d.nact += (size_t)(d.maxit + 2) * i; sl.d.qp_stat += o * 2;
         sl.d.xs32 += o * Nc * nx; sl.d.us32 += o * Nc; sl.d.xc32 += o * Nc * nx;
         sl.d.A32 += o * Nc * nx * nx; sl.d.B32 += o * Nc * nx; sl.d.C32 += o * Nc * nx;
+        if (d.wset) { sl.d.wset += o * 64; sl.d.wcnt += o; }
+        if (d.stamps) sl.d.stamps += o * 16;
         if (ns > 1) {
             if (hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess ||
                 hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) {

@@ -278,7 +278,7 @@ struct MpcQpArgs {
     const double *lA, *lB, *lC, *x0, *ymeas, *Xs, *Us;
     double *Ge, *Fe, *Le, *hv, *u, *eps, *xpred;
     int* status;
-    unsigned long long* stamps;   // optional diagnostics: 12 clock values per problem
+    unsigned long long* stamps;   // optional diagnostics: 16 clock values per problem
     MpcConst c;
 };
 
@@ -291,7 +291,7 @@ __global__ void mpc_qp_kernel(MpcQpArgs a) {
     const int Nc = NC ? NC : a.c.Nc, n = NC ? NC + 1 : mpc_nvar(Nc, a.c.slack), mt = NC ? 4 * NC + 2 : mpc_nrows(Nc, NX, a.c.mode);
     MpcLds L;
     L.carve(mpc_lds + (size_t)g * mpc_lds_doubles(Nc, NX, n, mt), Nc, NX, n, mt);
-    unsigned long long* st = a.stamps ? a.stamps + (size_t)prob * 12 : nullptr;
+    unsigned long long* st = a.stamps ? a.stamps + (size_t)prob * 16 : nullptr;
     if (st && gl == 0) st[0] = __builtin_amdgcn_s_memtime();
     for (int e = gl; e < Nc * NX * NX; e += GS) L.Ak[e] = a.lA[(size_t)prob * Nc * NX * NX + e];
     for (int e = gl; e < Nc * NX; e += GS) {
@@ -341,6 +341,12 @@ struct CtrlDev {
     float *xs32, *us32, *xc32, *A32, *B32, *C32;
     const float *enc, *hplain;
     int n_enc_in;
+    // long-horizon kernels: final working set of each controller's last QP solve (row ids, 64 per controller) and
+    // its size; null when the working set is not carried over
+    unsigned char* wset;
+    int* wcnt;
+    int warm;   // 0: the carried set is recorded but every solve starts cold (NMPC_QP_WARM=0)
+    unsigned long long* stamps;   // optional diagnostics (long-horizon kernels): 16 clock values per controller
 };
 
 struct RunPtrs {

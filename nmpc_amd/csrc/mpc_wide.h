@@ -44,22 +44,30 @@ __host__ __device__ inline int wide_kh(int Nc, int nx) { return nx != 2 ? 32 : (
 struct WideLds {
     double *Lm, *Lw, *Mi, *Al, *Gam, *Ak, *Bk, *Ck, *qd, *xi, *x0, *Xs, *Us, *uold, *hv, *invdL, *invdW, *Dp, *usol, *wbuf, *red;
     int* Wtab;
+    // The factor of the Hessian and Gamma (condensing, transform, recovery of z, prediction) and the working-set
+    // Gram matrix and inverse factor (active-set iteration only) are never live together: they share one region,
+    // and the former sit in registers while the iteration runs (wide_solve).
+    __host__ __device__ static int shared_doubles(int Nc, int nx, int KH) {
+        const int n = Nc + 1, a = 2 * KH * Nc + Nc * (Nc + 1) / 2 * nx, b = 2 * n * n;
+        return a > b ? a : b;
+    }
     __host__ __device__ static int doubles(int Nc, int nx, int KH) {
         const int n = Nc + 1, NPc = wide_cols(Nc), R = 2 * KH;
-        return R * Nc + 2 * n * n + R * NPc + Nc * (Nc + 1) / 2 * nx + Nc * nx * nx + 5 * Nc * nx + 4 + 2 * Nc + 2 * wide_npairs(Nc) + 2 +
-               R + n + NPc + n + 3 * 4 * 64 + 32 + 2 * n + 2;
+        return shared_doubles(Nc, nx, KH) + R * NPc + Nc * nx * nx + 5 * Nc * nx + 4 + 2 * Nc + 2 * wide_npairs(Nc) + 2 +
+               R + n + NPc + n + 3 * 4 * 64 + 64 + 2 * n + 2;
     }
     __device__ void carve(double* p, int Nc, int nx, int KH) {
         const int n = Nc + 1, NPc = wide_cols(Nc), R = 2 * KH;
-        Lm = p; p += R * Nc; Lw = p; p += n * n; Mi = p; p += n * n; Al = p; p += R * NPc; Gam = p; p += Nc * (Nc + 1) / 2 * nx;
+        Lm = p; Gam = p + R * Nc; Lw = p; Mi = p + n * n; p += shared_doubles(Nc, nx, KH); Al = p; p += R * NPc;
         Ak = p; p += Nc * nx * nx; Bk = p; p += Nc * nx; Ck = p; p += Nc * nx; qd = p; p += Nc * nx; xi = p; p += Nc * nx;
         Xs = p; p += Nc * nx; x0 = p; p += 4; Us = p; p += Nc; uold = p; p += Nc; hv = p; p += 2 * wide_npairs(Nc) + 2;
-        invdL = p; p += R; invdW = p; p += n; Dp = p; p += NPc; usol = p; p += n; wbuf = p; p += 3 * 4 * 64; red = p; p += 32;
+        invdL = p; p += R; invdW = p; p += n; Dp = p; p += NPc; usol = p; p += n; wbuf = p; p += 3 * 4 * 64; red = p; p += 64;
         Wtab = reinterpret_cast<int*>(p);     // n pair ids, then n signs as doubles behind them
     }
 };
 
-// red: [0..3] score, [4..7] slack of the candidate, [8..11] row (as double), [12] sp after a drop, [13] flag
+// red: [0..3] score, [4..7] slack of the candidate, [8..11] row (as double), [12] sp after a drop, [13] flag;
+// [16..47] the carried working set's row ids as bytes, one copy of 64 per wave
 __device__ __forceinline__ double dpp_swap1(double v) { return dpp_d<DPP_XOR1>(v); }
 
 // Cholesky of the leading n x n block of Lm (row-major, ld n, lower triangle valid; rows n .. NMAX-1 exist and
@@ -98,14 +106,19 @@ __device__ __forceinline__ bool wide_chol_regs(double* Lm, double* invd, int n) 
 
 struct WideDump { double *Ge, *Fe, *Le, *hv; };
 
+// Working set carried from one solve of a controller to its next (row ids 2 pair + sign bit, at most 64):
+// `in` / n_in the rows to start from (n_in = 0: cold start), `out` / n_out receive the final working set.
+struct WideWarm { const unsigned char* in; int n_in; unsigned char* out; int* n_out; };
+
 // On entry Ak, Bk, Ck, x0, Xs, Us are loaded (and a barrier passed).  On exit usol[0..Nc) = u, usol[Nc] = eps,
 // xi = predicted states; returns the solver status (uniform), *iters_out the active-set iterations.
 // st (diagnostics): clock stamps [0] entry, after [1] recurrences [2] qd [3] Hessian / rows [4] Cholesky
 // [5] transform [6] slack init [7] active-set loop [8] recovery of z [9] prediction; [10] iterations;
-// [11] the whole solve in ticks of the constant 100 MHz clock.
+// [11] the whole solve in ticks of the constant 100 MHz clock; the closed-loop kernel adds [12] kernel entry,
+// [13] kernel exit, [14] the LPV pass; [15] end of the warm start (between [6] and [7]).
 template <int NX, int KH>
 __device__ __forceinline__ int wide_solve(const MpcConst& c, WideLds& L, double ymeas, int* iters_out, const WideDump* dump,
-                                          unsigned long long* st = nullptr) {
+                                          unsigned long long* st = nullptr, const WideWarm* warm = nullptr) {
     constexpr int R = 2 * KH;
     const int tid = threadIdx.x, lane = tid & 63;
 #define WIDE_STAMP(i) do { if (st && tid == 0) st[i] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -167,7 +180,6 @@ __device__ __forceinline__ int wide_solve(const MpcConst& c, WideLds& L, double 
     } else {
         const int t3 = tid - 64, n3 = WIDE_THREADS - 64;
         for (int e = t3; e < R * NPc; e += n3) Al[e] = 0.0;
-        for (int e = t3; e < n * n; e += n3) L.Mi[e] = 0.0;
         for (int e = Nc * Nc + t3; e < R * Nc; e += n3) L.Lm[e] = 0.0;
         for (int e = Nc + t3; e < R; e += n3) L.invdL[e] = 0.0;
         for (int e = t3; e < 3 * 4 * 64; e += n3) L.wbuf[e] = 0.0;
@@ -337,6 +349,128 @@ __device__ __forceinline__ int wide_solve(const MpcConst& c, WideLds& L, double 
     double* kpb = L.wbuf + (4 + wave) * 64;
     double* lb = L.wbuf + (8 + wave) * 64;
     double* Mi = L.Mi;
+    // The factor of G and Gamma move to registers for the duration of the iteration; their LDS becomes the
+    // working set's Gram matrix and inverse factor.
+    constexpr int SAVE_N = (R * R + R * (R + 1) / 2 * NX + WIDE_THREADS - 1) / WIDE_THREADS;
+    const int save_len = R * Nc + Nc * (Nc + 1) / 2 * NX;
+    double saved[SAVE_N];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SAVE_N; ++i) {
+        const int e = tid + WIDE_THREADS * i;
+        saved[i] = L.Lm[e < save_len ? e : 0];
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += WIDE_THREADS) Mi[e] = 0.0;
+    // Gram matrix of the working set (whole workgroup), its Cholesky factor and M = Lw^-1 (wave 0); false if the
+    // rows are numerically dependent.  Every wave holds the same q, wpj, wsgj.
+    auto rebuild = [&]() -> bool {
+        double* Wsg = reinterpret_cast<double*>(L.Wtab + 2 * ((n + 1) / 2));
+        __syncthreads();               // every wave is done with the old inverse factor
+        if (wave == 0 && lane < q) { L.Wtab[lane] = wpj; Wsg[lane] = wsgj; }
+        __syncthreads();
+        for (int e = tid; e < q * (q + 1) / 2; e += WIDE_THREADS) {
+            int a_ = (int)((__builtin_sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+            while ((a_ + 1) * (a_ + 2) / 2 <= e) ++a_;
+            while (a_ * (a_ + 1) / 2 > e) --a_;
+            const int b_ = e - a_ * (a_ + 1) / 2;
+            const int wa = L.Wtab[a_], wb = L.Wtab[b_];
+            double acc = 0.0;
+#pragma unroll 4
+            for (int k = 0; k < Nc; ++k) acc = fma(Al[k * NPc + wa], Al[k * NPc + wb], acc);
+            L.Lw[a_ * n + b_] = fma(Wsg[a_] * Wsg[b_], acc, sig2);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const bool ok = chol_rows_lds(L.Lw, q, n, L.invdW);
+            g_sync();
+            if (ok && lane < q) {       // column `lane` of M = Lw^-1 by forward substitution
+                for (int i = 0; i < q; ++i) {
+                    double x = 0.0;
+                    if (i == lane) x = L.invdW[i];
+                    else if (i > lane) {
+                        double acc = 0.0;
+                        for (int k = lane; k < i; ++k) acc = fma(L.Lw[i * n + k], Mi[k * n + lane], acc);
+                        x = -acc * L.invdW[i];
+                    }
+                    Mi[i * n + lane] = x;
+                }
+            }
+            if (lane == 0) L.red[13] = ok ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        return L.red[13] != 0.0;
+    };
+    // Warm start: the rows of the controller's previous working set enter together.  With K their Gram matrix,
+    // the minimiser on their intersection has multipliers lambda = -K^-1 s_W (s = slacks at the unconstrained
+    // minimiser); members whose multiplier is not positive are dropped and the rest solved again, until all
+    // are positive - minimiser and set are then a valid state of the dual iteration, which goes on from
+    // there.  A numerically dependent set falls back to the cold start.
+    if (warm && warm->n_in > 0) {
+        q = warm->n_in < n ? warm->n_in : n;
+        {
+            const int rid = lane < q ? (int)warm->in[lane] : 0;
+            wpj = rid >> 1; wsgj = (rid & 1) ? -1.0 : 1.0;
+            if (lane >= q || wpj >= NP) { wpj = 0; wsgj = 1.0; }
+        }
+        if (has_row) L.hv[row] = s;                          // right-hand sides are spent: hv now holds s
+        while (q > 0) {
+            ++iters;
+            if (!rebuild()) { q = 0; break; }
+            const int iq = lane < q ? lane : 0;
+            g_sync();
+            kpb[lane] = lane < q ? L.hv[2 * wpj + (wsgj < 0.0 ? 1 : 0)] : 0.0;
+            g_sync();
+            double lj = 0.0;
+            {
+                const double* mr = Mi + iq * n;
+#pragma unroll 4
+                for (int j = 0; j < q; ++j) lj = fma(mr[j], kpb[j], lj);
+            }
+            if (lane >= q) lj = 0.0;
+            lb[lane] = lj;
+            g_sync();
+            double rj = 0.0;
+            {
+                const double* mc = Mi + iq;
+#pragma unroll 4
+                for (int i = 0; i < q; ++i) rj = fma(mc[i * n], lb[i], rj);
+            }
+            lamj = lane < q ? -rj : 0.0;
+            const bool keep_me = lane < q && lamj > 0.0;
+            const unsigned long long keep = __ballot(keep_me);
+            const int qn = __popcll(keep);
+            if (qn == q) break;
+            const int pos = __popcll(keep & ((1ull << lane) - 1ull));
+            g_sync();
+            if (keep_me) kpb[pos] = (double)(2 * wpj + (wsgj < 0.0 ? 1 : 0));
+            g_sync();
+            q = qn;
+            const int rid = lane < q ? (int)kpb[lane] : 0;
+            wpj = rid >> 1; wsgj = (rid & 1) ? -1.0 : 1.0; lamj = 0.0;
+        }
+        if (q > 0) {
+            const int kr = lane < Nc ? lane : 0;
+            const double* ak = Al + kr * NPc;
+            double a = 0.0;
+            const double ls = lamj * wsgj;
+#pragma unroll 4
+            for (int j = 0; j < q; ++j) a = fma(ak[__builtin_amdgcn_readlane(wpj, j)], readlane_d(ls, j), a);
+            const double lsum = wave_sum(lane < q ? lamj : 0.0);
+            g_sync();
+            avec[lane] = lane < Nc ? a : 0.0;
+            g_sync();
+            const double part = pair_dot(avec, 1);
+            if (has_row) s += (h ? -part : part) + sig2 * lsum;
+            for (int j = 0; j < q; ++j) {
+                const int rid = 2 * __builtin_amdgcn_readlane(wpj, j) + (readlane_d(wsgj, j) < 0.0 ? 1 : 0);
+                if (has_row && row == rid) { s = 0.0; inW = true; }
+            }
+        } else {
+            lamj = 0.0; wpj = 0; wsgj = 1.0;
+        }
+    }
+    WIDE_STAMP(15);
     for (;;) {
         double best = QP_INF; int bi = 0x7fffffff;
         if (has_row && !inW) { best = s * iscale; bi = row; }
@@ -427,49 +561,26 @@ __device__ __forceinline__ int wide_solve(const MpcConst& c, WideLds& L, double 
                 if (lane >= q) { lamj = 0.0; wpj = 0; wsgj = 1.0; }
                 // rebuild: K_ab = sg_a sg_b alpha_a . alpha_b + 1/rho by the whole workgroup, Lw = chol(K) and
                 // M = Lw^-1 by wave 0
-                double* Wsg = reinterpret_cast<double*>(L.Wtab + 2 * ((n + 1) / 2));
                 if (has_row && row == p) L.red[12] = s;
-                __syncthreads();               // every wave is done with the old inverse factor
-                if (wave == 0 && lane < q) { L.Wtab[lane] = wpj; Wsg[lane] = wsgj; }
-                __syncthreads();
-                for (int e = tid; e < q * (q + 1) / 2; e += WIDE_THREADS) {
-                    int a_ = (int)((__builtin_sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-                    while ((a_ + 1) * (a_ + 2) / 2 <= e) ++a_;
-                    while (a_ * (a_ + 1) / 2 > e) --a_;
-                    const int b_ = e - a_ * (a_ + 1) / 2;
-                    const int wa = L.Wtab[a_], wb = L.Wtab[b_];
-                    double acc = 0.0;
-#pragma unroll 4
-                    for (int k = 0; k < Nc; ++k) acc = fma(Al[k * NPc + wa], Al[k * NPc + wb], acc);
-                    L.Lw[a_ * n + b_] = fma(Wsg[a_] * Wsg[b_], acc, sig2);
-                }
-                __syncthreads();
-                if (wave == 0) {
-                    const bool ok = chol_rows_lds(L.Lw, q, n, L.invdW);
-                    g_sync();
-                    if (ok && lane < q) {       // column `lane` of M = Lw^-1 by forward substitution
-                        for (int i = 0; i < q; ++i) {
-                            double x = 0.0;
-                            if (i == lane) x = L.invdW[i];
-                            else if (i > lane) {
-                                double acc = 0.0;
-                                for (int k = lane; k < i; ++k) acc = fma(L.Lw[i * n + k], Mi[k * n + lane], acc);
-                                x = -acc * L.invdW[i];
-                            }
-                            Mi[i * n + lane] = x;
-                        }
-                    }
-                    if (lane == 0) L.red[13] = ok ? 1.0 : 0.0;
-                }
-                __syncthreads();
-                if (L.red[13] == 0.0) { status = 2; break; }
+                if (!rebuild()) { status = 2; break; }
                 sp = L.red[12];
             }
         }
         if (status) break;
     }
+    if (warm && warm->out && wave == 0) {
+        const int qo = status == 0 ? q : 0;
+        if (lane < qo) warm->out[lane] = (unsigned char)(2 * wpj + (wsgj < 0.0 ? 1 : 0));
+        if (lane == 0) *warm->n_out = qo;
+    }
     // ---- P9: z from the multipliers: L' z = zt_unc + Nt_W lam; wave 0 solves with column k of L in lane k's
     //          registers, the slack variable is separate
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SAVE_N; ++i) {
+        const int e = tid + WIDE_THREADS * i;
+        if (e < save_len) L.Lm[e] = saved[i];
+    }
     __syncthreads();
     WIDE_STAMP(7);
     if (wave == 0) {
@@ -534,7 +645,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void mpc_qp_wide_kernel(MpcQpArgs a) 
                   a.Le ? a.Le + (size_t)prob * mt * n : nullptr, a.hv ? a.hv + (size_t)prob * mt : nullptr};
     const bool want_dump = a.Ge || a.Fe || a.Le || a.hv;
     const int st = wide_solve<NX, KH>(a.c, L, a.ymeas ? a.ymeas[prob] : 0.0, nullptr, want_dump ? &dump : nullptr,
-                                      a.stamps ? a.stamps + (size_t)prob * 12 : nullptr);
+                                      a.stamps ? a.stamps + (size_t)prob * 16 : nullptr);
     if (a.u) for (int e = tid; e < Nc; e += WIDE_THREADS) a.u[(size_t)prob * Nc + e] = L.usol[e];
     if (a.xpred) for (int e = tid; e < Nc * NX; e += WIDE_THREADS) a.xpred[(size_t)prob * Nc * NX + e] = L.xi[e];
     if (tid == 0) {
@@ -551,6 +662,8 @@ __global__ __launch_bounds__(WIDE_THREADS) void mpc_solve_wide_kernel(CtrlDev d,
     if (gid >= count) return;
     const int b = it == 0 ? gid : d.act[(size_t)it * d.B + gid];
     const int Nc = d.Nc, ntot = d.n_sim + Nc;
+    unsigned long long* stp = d.stamps ? d.stamps + (size_t)b * 16 : nullptr;
+    if (stp && tid == 0) stp[12] = __builtin_amdgcn_s_memtime();
     WideLds L;
     L.carve(mpc_lds, Nc, NX, KH);
     for (int e = tid; e < Nc * NX * NX; e += WIDE_THREADS) L.Ak[e] = (double)d.A32[(size_t)b * Nc * NX * NX + e];
@@ -565,9 +678,40 @@ __global__ __launch_bounds__(WIDE_THREADS) void mpc_solve_wide_kernel(CtrlDev d,
         L.uold[e] = d.uplan[(size_t)b * Nc + e];
     }
     for (int e = tid; e < NX; e += WIDE_THREADS) L.x0[e] = d.x0n[(size_t)b * NX + e];
+    // The working set of this controller's previous solve is the starting guess.  Later passes of a step solve
+    // a QP with the same rows; the first pass of a step inherits the last step's set moved one stage forward:
+    // input rows u_i -> u_{i-1}, output rows y_j -> y_{j-1} (the new y_0 is a measurement: not carried), and
+    // rows of the last stage stay on the last stage as well (the plan's tail is repeated by the shift).
+    WideWarm warm{nullptr, 0, nullptr, nullptr};
+    if (d.wset) {
+        unsigned char* ws = d.wset + (size_t)b * 64;
+        unsigned char* wl = reinterpret_cast<unsigned char*>(L.red + 16) + (tid >> 6) * 64;   // this wave's copy
+        int cnt = d.wcnt[b];
+        cnt = cnt < 0 ? 0 : (cnt > Nc + 1 ? Nc + 1 : cnt);
+        const int lane = tid & 63;
+        int r0 = lane < cnt ? (int)ws[lane] : -1, r1 = -1;
+        if (it == 0 && r0 >= 0) {
+            const int p = r0 >> 1, hbit = r0 & 1;
+            int p0 = -1, p1 = -1;
+            if (p == 2 * Nc) { p0 = 2 * Nc - 1; p1 = 2 * Nc; }                   // y_Nc -> y_{Nc-1}, y_Nc
+            else if (p & 1) { p0 = p >= 5 ? p - 2 : -1; }                          // y_j -> y_{j-1}, j >= 2
+            else { p0 = p >= 2 ? p - 2 : -1; if (p == 2 * Nc - 2) p1 = p; }      // u_i -> u_{i-1}; u_{Nc-1} twice
+            if (Nc < 2) { p0 = -1; p1 = -1; }
+            r0 = p0 >= 0 ? 2 * p0 + hbit : -1;
+            r1 = p1 >= 0 ? 2 * p1 + hbit : -1;
+        }
+        const unsigned long long m0 = __ballot(r0 >= 0), m1 = __ballot(r1 >= 0);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const int c0 = __popcll(m0), pos0 = __popcll(m0 & below), pos1 = c0 + __popcll(m1 & below);
+        if (r0 >= 0 && pos0 < 64) wl[pos0] = (unsigned char)r0;
+        if (r1 >= 0 && pos1 < 64) wl[pos1] = (unsigned char)r1;
+        int tot = c0 + __popcll(m1);
+        tot = tot > Nc + 1 ? Nc + 1 : tot;
+        warm.in = wl; warm.n_in = d.warm ? tot : 0; warm.out = ws; warm.n_out = d.wcnt + b;
+    }
     __syncthreads();
     int qp_it = 0;
-    const int st = wide_solve<NX, KH>(d.c, L, d.ymeas[b], &qp_it, nullptr);
+    const int st = wide_solve<NX, KH>(d.c, L, d.ymeas[b], &qp_it, nullptr, stp, &warm);
     double du = 0.0;
     for (int e = tid; e < Nc; e += WIDE_THREADS) {
         const double un = L.usol[e], dd = un - L.uold[e];
@@ -595,6 +739,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void mpc_solve_wide_kernel(CtrlDev d,
             }
         }
     }
+    if (stp && tid == 0) { stp[13] = __builtin_amdgcn_s_memtime(); stp[14] = (unsigned long long)it; }
 }
 
 // host side (mpc_wide.hip, mpc_wide34.hip)
