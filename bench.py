@@ -295,6 +295,12 @@ def closed_loop_bench(args, cfgname, rank, world, dev, shard):
     if stamps is not None and rank == 0:
         st = stamps.cpu().numpy().astype(np.float64)
         st = st[st[:, 13] > 0]
+        why = (stamps.cpu().numpy()[:, 10] >> 32)[stamps.cpu().numpy()[:, 13] > 0]
+        st[:, 10] = stamps.cpu().numpy()[:, 10][stamps.cpu().numpy()[:, 13] > 0] & 0xffffffff
+        for p_ in range(int(st[:, 14].max()) + 1):
+            sel = st[:, 14] == p_
+            sys.stderr.write("  last solve in pass %d: %d controllers; fast path taken %.3f, multiplier <= 0 %.3f, row violated %.3f, not tried %.3f\n"
+                             % (p_, sel.sum(), (why[sel] == 0).mean(), (why[sel] == 1).mean(), (why[sel] == 2).mean(), (why[sel] == 3).mean()))
         names = ["recurrences", "qd", "hessian/rows", "cholesky", "transform", "slack init", "warm start", "active-set loop", "recover z",
                  "predict"]
         seq = np.stack([st[:, 0], st[:, 1], st[:, 2], st[:, 3], st[:, 4], st[:, 5], st[:, 6], st[:, 15], st[:, 7], st[:, 8], st[:, 9]], 1)

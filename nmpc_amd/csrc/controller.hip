@@ -410,7 +410,8 @@ extern "C" int nmpc_ctrl_create(nmpc_ctrl** out, const nmpc_model* m, const nmpc
         // long-horizon kernels carry each controller's working set from one QP solve to the next
         rc |= alloc((void**)&d.wset, sb * 64); rc |= alloc((void**)&d.wcnt, sb * 4);
         const char* e = getenv("NMPC_QP_WARM");
-        d.warm = (e && atoi(e) == 0) ? 0 : 1;
+        d.warm = e ? atoi(e) : 2;          // 0 cold starts, 1 warm-started iteration, 2 verified fast path first
+        if (d.warm < 0 || d.warm > 2) d.warm = 2;
     }
     if (const char* e = getenv("NMPC_MPC_STAMPS")) {      // diagnostics: 16 clock stamps per controller (device memory)
         void* p = (void*)strtoull(e, nullptr, 16);

@@ -345,7 +345,8 @@ struct CtrlDev {
     // its size; null when the working set is not carried over
     unsigned char* wset;
     int* wcnt;
-    int warm;   // 0: the carried set is recorded but every solve starts cold (NMPC_QP_WARM=0)
+    int warm;   // NMPC_QP_WARM: 0 the carried set is recorded but every solve starts cold, 1 warm-started iteration,
+                // 2 (default) the verified fast path first
     unsigned long long* stamps;   // optional diagnostics (long-horizon kernels): 16 clock values per controller
 };
 

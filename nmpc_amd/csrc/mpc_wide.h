@@ -28,6 +28,8 @@
 // The algorithm is the Goldfarb-Idnani iteration of qp_gi.h (same pivoting rule, tolerances and status
 // codes); only the data layout and the work distribution differ.
 #pragma once
+#include <type_traits>
+
 #include "mpc_kernels.h"
 
 namespace nmpc {
@@ -73,6 +75,38 @@ __device__ __forceinline__ double dpp_swap1(double v) { return dpp_d<DPP_XOR1>(v
 // Cholesky of the leading n x n block of Lm (row-major, ld n, lower triangle valid; rows n .. NMAX-1 exist and
 // are zero), one wave, row i in the registers of lane i.  Rows take the update over their whole tail: entries
 // right of the diagonal are never read.  invd[j] = 1 / L[j][j].
+// The pivot column's entries are fetched eight at a time and only then used: one wave alone on its SIMD pays the
+// full latency of every v_readlane -> v_fma pair that is issued back to back.  (Template recursion instead of
+// loops: every register index is a compile-time constant by construction.)
+template <int J, int C0, int NMAX>
+__device__ __forceinline__ void wide_chol_tail(double (&row)[NMAX]) {
+    if constexpr (C0 < NMAX) {
+        constexpr int N = NMAX - C0 < 8 ? NMAX - C0 : 8;
+        double pv[N];
+#pragma unroll
+        for (int u = 0; u < N; ++u) pv[u] = readlane_d(row[J], C0 + u);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < N; ++u) row[C0 + u] = fma(-row[J], pv[u], row[C0 + u]);
+        __builtin_amdgcn_sched_barrier(0);
+        wide_chol_tail<J, C0 + 8, NMAX>(row);
+    }
+}
+template <int J, int NMAX>
+__device__ __forceinline__ void wide_chol_steps(double (&row)[NMAX], double* invd, int n, bool& ok) {
+    if constexpr (J < NMAX) {
+        if (J < n) {                                  // uniform
+            const int lane = threadIdx.x & 63;
+            const double d = readlane_d(row[J], J);
+            if (!(d > 0.0)) ok = false;
+            const double inv = rsqrt_d(d > 0.0 ? d : 1.0);
+            row[J] *= inv;
+            if (lane == 0) invd[J] = inv;
+            wide_chol_tail<J, J + 1, NMAX>(row);
+        }
+        wide_chol_steps<J + 1, NMAX>(row, invd, n, ok);
+    }
+}
 template <int NMAX>
 __device__ __forceinline__ bool wide_chol_regs(double* Lm, double* invd, int n) {
     const int lane = threadIdx.x & 63;
@@ -84,18 +118,7 @@ __device__ __forceinline__ bool wide_chol_regs(double* Lm, double* invd, int n) 
         row[c] = (lane < n && c <= lane) ? v : 0.0;
     }
     bool ok = true;
-#pragma unroll
-    for (int j = 0; j < NMAX; ++j) {
-        if (j < n) {                                  // uniform
-            const double d = readlane_d(row[j], j);
-            if (!(d > 0.0)) ok = false;
-            const double inv = rsqrt_d(d > 0.0 ? d : 1.0);
-            row[j] *= inv;
-            if (lane == 0) invd[j] = inv;
-#pragma unroll
-            for (int c = j + 1; c < NMAX; ++c) row[c] = fma(-row[j], readlane_d(row[j], c), row[c]);
-        }
-    }
+    wide_chol_steps<0, NMAX>(row, invd, n, ok);
     if (lane < n) {
 #pragma unroll
         for (int c = 0; c < NMAX; ++c)
@@ -108,7 +131,7 @@ struct WideDump { double *Ge, *Fe, *Le, *hv; };
 
 // Working set carried from one solve of a controller to its next (row ids 2 pair + sign bit, at most 64):
 // `in` / n_in the rows to start from (n_in = 0: cold start), `out` / n_out receive the final working set.
-struct WideWarm { const unsigned char* in; int n_in; unsigned char* out; int* n_out; };
+struct WideWarm { const unsigned char* in; int n_in; unsigned char* out; int* n_out; int fast; };
 
 // On entry Ak, Bk, Ck, x0, Xs, Us are loaded (and a barrier passed).  On exit usol[0..Nc) = u, usol[Nc] = eps,
 // xi = predicted states; returns the solver status (uniform), *iters_out the active-set iterations.
@@ -279,40 +302,17 @@ __device__ __forceinline__ int wide_solve(const MpcConst& c, WideLds& L, double 
         return 3;
     }
     WIDE_STAMP(4);
-    // ---- P6: alpha = L_G^-1 a for every pair and zt = -L_G^-1 F (column NP): right-looking forward
-    //          substitution.  Lane 2 i + h holds rows k = 2 m + h of column i in areg[m]; row l's solution is
-    //          formed by the lane that owns it, passed to its partner, and both update their later rows.
+    // ---- rows of the (untransformed) columns in registers: lane 2 i + h holds rows k = 2 m + h of column i in
+    //      areg[m] (pairs i < NP, then the linear term, which enters as right-hand side -q)
     const int ci = tid >> 1, h = tid & 1;
     const bool has_col = ci <= NP;
     const int cc = has_col ? ci : NP;
     double areg[KH];
     {
-        const double sgn = ci == NP ? -1.0 : 1.0;            // the linear term q enters as right-hand side -q
-        const double dreg = L.invdL[lane < R ? lane : 0];    // lane l: 1 / L[l][l]
+        const double sgn = ci == NP ? -1.0 : 1.0;
 #pragma unroll
         for (int m = 0; m < KH; ++m) areg[m] = sgn * Al[(2 * m + h) * NPc + cc];
-        const double* Lh = L.Lm + h * Nc;                    // row 2 m + h of L starts at Lh + 2 m Nc
-#pragma unroll
-        for (int l = 0; l < R; ++l) {
-            if (l >= Nc) continue;                          // uniform; padding rows have nothing to solve
-            const int ml = l >> 1, hl = l & 1;
-            const double ym = areg[ml] * readlane_d(dreg, l);
-            const double yo = dpp_swap1(ym);
-            const bool mine = h == hl;
-            const double y = mine ? ym : yo;
-            areg[ml] = mine ? y : areg[ml];
-            if (mine && has_col && l < Nc) Al[l * NPc + cc] = y;
-#pragma unroll
-            for (int m = (l + 1) >> 1; m < KH; ++m) {
-                double coef = Lh[2 * m * Nc + l];
-                if (2 * m == l) coef = h ? coef : 0.0;       // row 2 m + 0 = l is the pivot row itself
-                areg[m] = fma(-coef, y, areg[m]);
-            }
-        }
     }
-    __syncthreads();
-    WIDE_STAMP(5);
-    // ---- P7: slacks s = h + nt . zt_unc (the slack component of zt_unc is zero).  Lane 2 p + h owns row h of pair p.
     const int row = tid, pi = tid >> 1;
     const bool has_row = pi < NP;
     const double sigma = 1.0 / sqrt(c.rho), sig2 = 1.0 / c.rho;
@@ -330,16 +330,6 @@ __device__ __forceinline__ int wide_solve(const MpcConst& c, WideLds& L, double 
         part += dpp_swap1(part);
         return part;
     };
-    {
-        const double part = pair_dot(Al + NP, NPc);
-        if (has_row) {
-            const double hval = L.hv[row];
-            iscale = 1.0 / (1.0 + fabs(hval));
-            s = hval + (h ? -part : part);
-        }
-    }
-    WIDE_STAMP(6);
-    // ---- P8: dual active-set iteration
     int q = 0, iters = 0, status = 0;
     double lamj = 0.0, wsgj = 1.0;      // lane j < q of EVERY wave: multiplier, pair and sign of working-set member j
     int wpj = 0;
@@ -349,262 +339,480 @@ __device__ __forceinline__ int wide_solve(const MpcConst& c, WideLds& L, double 
     double* kpb = L.wbuf + (4 + wave) * 64;
     double* lb = L.wbuf + (8 + wave) * 64;
     double* Mi = L.Mi;
-    // The factor of G and Gamma move to registers for the duration of the iteration; their LDS becomes the
-    // working set's Gram matrix and inverse factor.
-    constexpr int SAVE_N = (R * R + R * (R + 1) / 2 * NX + WIDE_THREADS - 1) / WIDE_THREADS;
-    const int save_len = R * Nc + Nc * (Nc + 1) / 2 * NX;
-    double saved[SAVE_N];
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < SAVE_N; ++i) {
-        const int e = tid + WIDE_THREADS * i;
-        saved[i] = L.Lm[e < save_len ? e : 0];
-    }
-    __syncthreads();
-    for (int e = tid; e < n * n; e += WIDE_THREADS) Mi[e] = 0.0;
-    // Gram matrix of the working set (whole workgroup), its Cholesky factor and M = Lw^-1 (wave 0); false if the
-    // rows are numerically dependent.  Every wave holds the same q, wpj, wsgj.
-    auto rebuild = [&]() -> bool {
-        double* Wsg = reinterpret_cast<double*>(L.Wtab + 2 * ((n + 1) / 2));
-        __syncthreads();               // every wave is done with the old inverse factor
-        if (wave == 0 && lane < q) { L.Wtab[lane] = wpj; Wsg[lane] = wsgj; }
-        __syncthreads();
-        for (int e = tid; e < q * (q + 1) / 2; e += WIDE_THREADS) {
-            int a_ = (int)((__builtin_sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-            while ((a_ + 1) * (a_ + 2) / 2 <= e) ++a_;
-            while (a_ * (a_ + 1) / 2 > e) --a_;
-            const int b_ = e - a_ * (a_ + 1) / 2;
-            const int wa = L.Wtab[a_], wb = L.Wtab[b_];
-            double acc = 0.0;
-#pragma unroll 4
-            for (int k = 0; k < Nc; ++k) acc = fma(Al[k * NPc + wa], Al[k * NPc + wb], acc);
-            L.Lw[a_ * n + b_] = fma(Wsg[a_] * Wsg[b_], acc, sig2);
-        }
-        __syncthreads();
+    // z from the multipliers: L' z = zt_unc + Nt_W lam; wave 0 solves with column k of L in lane k's registers,
+    // the slack variable is separate (needs the factor of G in LDS and the transformed columns of the working set
+    // and of the linear term in the pair table)
+    auto recover_z = [&]() {
         if (wave == 0) {
-            const bool ok = chol_rows_lds(L.Lw, q, n, L.invdW);
-            g_sync();
-            if (ok && lane < q) {       // column `lane` of M = Lw^-1 by forward substitution
-                for (int i = 0; i < q; ++i) {
-                    double x = 0.0;
-                    if (i == lane) x = L.invdW[i];
-                    else if (i > lane) {
-                        double acc = 0.0;
-                        for (int k = lane; k < i; ++k) acc = fma(L.Lw[i * n + k], Mi[k * n + lane], acc);
-                        x = -acc * L.invdW[i];
-                    }
-                    Mi[i * n + lane] = x;
-                }
-            }
-            if (lane == 0) L.red[13] = ok ? 1.0 : 0.0;
-        }
-        __syncthreads();
-        return L.red[13] != 0.0;
-    };
-    // Warm start: the rows of the controller's previous working set enter together.  With K their Gram matrix,
-    // the minimiser on their intersection has multipliers lambda = -K^-1 s_W (s = slacks at the unconstrained
-    // minimiser); members whose multiplier is not positive are dropped and the rest solved again, until all
-    // are positive - minimiser and set are then a valid state of the dual iteration, which goes on from
-    // there.  A numerically dependent set falls back to the cold start.
-    if (warm && warm->n_in > 0) {
-        q = warm->n_in < n ? warm->n_in : n;
-        {
-            const int rid = lane < q ? (int)warm->in[lane] : 0;
-            wpj = rid >> 1; wsgj = (rid & 1) ? -1.0 : 1.0;
-            if (lane >= q || wpj >= NP) { wpj = 0; wsgj = 1.0; }
-        }
-        if (has_row) L.hv[row] = s;                          // right-hand sides are spent: hv now holds s
-        while (q > 0) {
-            ++iters;
-            if (!rebuild()) { q = 0; break; }
-            const int iq = lane < q ? lane : 0;
-            g_sync();
-            kpb[lane] = lane < q ? L.hv[2 * wpj + (wsgj < 0.0 ? 1 : 0)] : 0.0;
-            g_sync();
-            double lj = 0.0;
-            {
-                const double* mr = Mi + iq * n;
-#pragma unroll 4
-                for (int j = 0; j < q; ++j) lj = fma(mr[j], kpb[j], lj);
-            }
-            if (lane >= q) lj = 0.0;
-            lb[lane] = lj;
-            g_sync();
-            double rj = 0.0;
-            {
-                const double* mc = Mi + iq;
-#pragma unroll 4
-                for (int i = 0; i < q; ++i) rj = fma(mc[i * n], lb[i], rj);
-            }
-            lamj = lane < q ? -rj : 0.0;
-            const bool keep_me = lane < q && lamj > 0.0;
-            const unsigned long long keep = __ballot(keep_me);
-            const int qn = __popcll(keep);
-            if (qn == q) break;
-            const int pos = __popcll(keep & ((1ull << lane) - 1ull));
-            g_sync();
-            if (keep_me) kpb[pos] = (double)(2 * wpj + (wsgj < 0.0 ? 1 : 0));
-            g_sync();
-            q = qn;
-            const int rid = lane < q ? (int)kpb[lane] : 0;
-            wpj = rid >> 1; wsgj = (rid & 1) ? -1.0 : 1.0; lamj = 0.0;
-        }
-        if (q > 0) {
             const int kr = lane < Nc ? lane : 0;
+            double creg[R];
+#pragma unroll
+            for (int i = 0; i < R; ++i) creg[i] = L.Lm[i * Nc + kr];          // L[i][k]; rows >= Nc are zero
             const double* ak = Al + kr * NPc;
-            double a = 0.0;
+            double v = ak[NP];
             const double ls = lamj * wsgj;
 #pragma unroll 4
-            for (int j = 0; j < q; ++j) a = fma(ak[__builtin_amdgcn_readlane(wpj, j)], readlane_d(ls, j), a);
+            for (int j = 0; j < q; ++j) v = fma(ak[__builtin_amdgcn_readlane(wpj, j)], readlane_d(ls, j), v);
+            if (lane >= Nc) v = 0.0;
             const double lsum = wave_sum(lane < q ? lamj : 0.0);
+            const double invl = L.invdL[lane < R ? lane : 0];
+            double xres = 0.0;
+#pragma unroll
+            for (int i = R - 1; i >= 0; --i) {
+                const double xv = readlane_d(v, i) * readlane_d(invl, i);     // zero for the padding rows
+                if (lane == i) xres = xv;
+                v = lane < i ? fma(-creg[i], xv, v) : v;
+            }
+            if (lane < Nc) L.usol[lane] = xres;
+            if (lane == 0) L.usol[Nc] = sig2 * lsum;
+        }
+    };
+    // ---- Fast path.  The previous working set W of this controller is usually the optimal one: transform only its
+    //      columns and the linear term, solve K lambda = -s_W for the multipliers (K = Gram matrix of W), recover z
+    //      and CHECK it - every multiplier positive, every row satisfied to the tolerance of the iteration below.
+    //      Then z is the optimum of the strictly convex QP and the transform of the other ~100 columns, their
+    //      slacks and the iteration are not needed; otherwise the columns are put back and the full algorithm runs.
+    //      Members whose multiplier comes out non-positive are dropped and the (small) system solved again, up to
+    //      three times: a constraint that has just become inactive does not cost the full algorithm.
+    bool fast_done = false;
+    int fast_why = 3;                    // diagnostics: 0 fast path taken, 1 a multiplier not positive, 2 a row violated, 3 not tried
+    auto fast_try = [&](auto fqc) -> bool {
+        constexpr int FQ = decltype(fqc)::value, CW = (FQ + 1 + 3) / 4;
+        const int q0 = warm->n_in, nfc = q0 + 1;
+        const int kr = lane < Nc ? lane : 0;
+        unsigned char* fl = reinterpret_cast<unsigned char*>(L.red + 48);   // the rows in play (one list for all waves)
+        double* kb = L.wbuf;                                // K, then its factor: packed lower triangle
+        double* rhs = L.wbuf + FQ * (FQ + 1) / 2;           // s_W in, multipliers out
+        double ycol[CW], orig[CW];
+        int colid[CW];
+        if (wave == 0 && lane < q0) fl[lane] = warm->in[lane];
+        __syncthreads();                                     // every areg load is done before a column changes
+#pragma unroll
+        for (int cw = 0; cw < CW; ++cw) {                    // wave w: members w, w + 4, ..; the linear term comes last
+            const int j = wave + 4 * cw;
+            const bool on = j < nfc;
+            const int col = (on && j < q0) ? ((int)fl[j] >> 1) : NP;
+            colid[cw] = on ? (col < NP ? col : NP) : -1;
+            const double v = Al[kr * NPc + (colid[cw] >= 0 ? colid[cw] : NP)];
+            orig[cw] = v;
+            ycol[cw] = (on && lane < Nc) ? ((j < q0) ? v : -v) : 0.0;
+        }
+        __syncthreads();                                     // a column shared by two members is read before either writes
+        {   // forward substitution, lane = row: w_k -= (L[k][l] / L[l][l]) w_l for k > l, y = w / diag at the end.
+            // The lane's row of L is fetched up front so that no step waits for LDS.
+            const double dreg = L.invdL[lane < R ? lane : 0];
+            double lrow[R];
+#pragma unroll
+            for (int l = 0; l < R; ++l) lrow[l] = L.Lm[kr * Nc + (l < kr ? l : kr)];
+#pragma unroll
+            for (int l = 0; l < R; ++l) {
+                if (l >= Nc) continue;                      // uniform
+                const double coef = lane > l ? lrow[l] * readlane_d(dreg, l) : 0.0;
+                double pv[CW];
+#pragma unroll
+                for (int cw = 0; cw < CW; ++cw) pv[cw] = readlane_d(ycol[cw], l);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int cw = 0; cw < CW; ++cw) ycol[cw] = fma(-coef, pv[cw], ycol[cw]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int cw = 0; cw < CW; ++cw) ycol[cw] *= dreg;
+        }
+#pragma unroll
+        for (int cw = 0; cw < CW; ++cw)
+            if (lane < Nc && colid[cw] >= 0) Al[lane * NPc + colid[cw]] = ycol[cw];
+        int qf = q0;
+        bool ok = false;
+        for (int round = 0; round < 3; ++round) {
+            ++iters;
+            __syncthreads();
+            // Gram matrix and right-hand side s_W = h_W + sg (alpha_W . zt_unc) by the whole workgroup
+            const int nk = qf * (qf + 1) / 2;
+            for (int e = tid; e < nk + qf; e += WIDE_THREADS) {
+                int a_ = 0, b_ = 0;
+                if (e < nk) {
+                    a_ = (int)((__builtin_sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+                    while ((a_ + 1) * (a_ + 2) / 2 <= e) ++a_;
+                    while (a_ * (a_ + 1) / 2 > e) --a_;
+                    b_ = e - a_ * (a_ + 1) / 2;
+                } else { a_ = e - nk; }
+                const int ra = (int)fl[a_], rb = (int)fl[b_];
+                const int wa = ra >> 1, wb = e < nk ? (rb >> 1) : NP;
+                const double sga = (ra & 1) ? -1.0 : 1.0, sgb = (rb & 1) ? -1.0 : 1.0;
+                double acc = 0.0;
+#pragma unroll 4
+                for (int k = 0; k < Nc; ++k) acc = fma(Al[k * NPc + wa], Al[k * NPc + wb], acc);
+                if (e < nk) kb[e] = fma(sga * sgb, acc, sig2);
+                else rhs[a_] = L.hv[ra] + sga * acc;
+            }
+            __syncthreads();
+            if (wave == 0) {       // Cholesky of K with row i in lane i's registers, the two triangular solves
+                const int lr = lane < qf ? lane : 0;
+                double krow[FQ];
+#pragma unroll
+                for (int cx = 0; cx < FQ; ++cx) {
+                    const double v = kb[lr * (lr + 1) / 2 + (cx <= lr ? cx : lr)];
+                    krow[cx] = (lane < qf && cx <= lane) ? v : (cx == lane ? 1.0 : 0.0);
+                }
+                bool okc = true;
+                wide_chol_steps<0, FQ>(krow, L.invdW, qf, okc);
+                g_sync();
+#pragma unroll
+                for (int cx = 0; cx < FQ; ++cx)
+                    if (lane < qf && cx <= lane) kb[lane * (lane + 1) / 2 + cx] = krow[cx];
+                g_sync();
+                const double invd = L.invdW[lr];
+                double v = lane < qf ? -rhs[lr] : 0.0;       // forward: Lk y = -s_W
+#pragma unroll
+                for (int j = 0; j < FQ; ++j) {
+                    if (j < qf) {
+                        const double yj = readlane_d(v, j) * readlane_d(invd, j);
+                        v = lane == j ? yj : (lane > j ? fma(-krow[j], yj, v) : v);
+                    }
+                }
+                double ktr[FQ];                              // column `lane` of the factor: L[j][lane], j >= lane
+#pragma unroll
+                for (int j = 0; j < FQ; ++j) ktr[j] = (j < qf && lane <= j) ? kb[j * (j + 1) / 2 + lane] : 0.0;
+#pragma unroll
+                for (int j = FQ - 1; j >= 0; --j) {          // backward: Lk' lambda = y
+                    if (j < qf) {
+                        const double xj = readlane_d(v, j) * readlane_d(invd, j);
+                        v = lane == j ? xj : (lane < j ? fma(-ktr[j], xj, v) : v);
+                    }
+                }
+                const bool keep_me = lane < qf && v > 0.0;
+                const unsigned long long keep = __ballot(keep_me);
+                const int qn = __popcll(keep);
+                int state = 0;                               // 0 solved, 1 members dropped: solve again, 2 give up
+                if (!okc) state = 2;
+                else if (qn < qf) {
+                    state = 1;
+                    const int rid = (int)fl[lr];
+                    const int pos = __popcll(keep & ((1ull << lane) - 1ull));
+                    g_sync();
+                    if (keep_me) fl[pos] = (unsigned char)rid;
+                } else if (lane < qf) rhs[lane] = v;
+                if (lane == 0) { L.red[5] = (double)state; L.red[6] = (double)qn; }
+            }
+            __syncthreads();
+            const int state = (int)L.red[5];
+            qf = (int)L.red[6];
+            if (state != 1) { ok = state == 0; break; }
+        }
+        fast_why = ok ? 0 : 1;
+        WIDE_STAMP(5);
+        if (ok) {                                            // uniform over the workgroup
+            q = qf;
+            const int rid = lane < q ? (int)fl[lane] : 0;
+            wpj = rid >> 1; wsgj = (rid & 1) ? -1.0 : 1.0; lamj = lane < q ? rhs[lane] : 0.0;
+            if (lane >= q) { wpj = 0; wsgj = 1.0; }
+            recover_z();
+            __syncthreads();
+            // rows in original coordinates: slack = h + (-+) a'u + eps
             g_sync();
-            avec[lane] = lane < Nc ? a : 0.0;
+            avec[lane] = lane < Nc ? L.usol[lane] : 0.0;
             g_sync();
             const double part = pair_dot(avec, 1);
-            if (has_row) s += (h ? -part : part) + sig2 * lsum;
-            for (int j = 0; j < q; ++j) {
-                const int rid = 2 * __builtin_amdgcn_readlane(wpj, j) + (readlane_d(wsgj, j) < 0.0 ? 1 : 0);
-                if (has_row && row == rid) { s = 0.0; inW = true; }
+            bool viol = false;
+            if (has_row) {
+                const double hval = L.hv[row];
+                const double sv = hval + (h ? -part : part) + L.usol[Nc];
+                viol = sv * (1.0 / (1.0 + fabs(hval))) < -1e-10;
             }
-        } else {
-            lamj = 0.0; wpj = 0; wsgj = 1.0;
+            const bool any = __ballot(viol) != 0ull;
+            if (lane == 0) L.red[wave] = any ? 1.0 : 0.0;
+            __syncthreads();
+            ok = (L.red[0] + L.red[1]) + (L.red[2] + L.red[3]) == 0.0;
+            if (!ok) fast_why = 2;
+            __syncthreads();                                 // red is reused below
         }
-    }
-    WIDE_STAMP(15);
-    for (;;) {
-        double best = QP_INF; int bi = 0x7fffffff;
-        if (has_row && !inW) { best = s * iscale; bi = row; }
-        g_argmin<64>(best, bi);
-        if (has_row && row == bi) L.red[4 + wave] = s;
-        if (lane == 0) { L.red[wave] = best; L.red[8 + wave] = (double)bi; }
-        __syncthreads();
-        double gb = L.red[0], sp = L.red[4]; int p = (int)L.red[8];
+        if (!ok) {                                           // put the columns back; areg still holds the untransformed rows
 #pragma unroll
-        for (int w = 1; w < 4; ++w) {
-            const double v = L.red[w]; const int vi = (int)L.red[8 + w];
-            if (v < gb || (v == gb && vi < p)) { gb = v; p = vi; sp = L.red[4 + w]; }
+            for (int cw = 0; cw < CW; ++cw)
+                if (lane < Nc && colid[cw] >= 0) Al[lane * NPc + colid[cw]] = orig[cw];
+            q = 0; lamj = 0.0; wpj = 0; wsgj = 1.0;
+            __syncthreads();
         }
-        if (!(gb < -1e-10)) break;
-        const int pp = p >> 1;
-        const double sgp = (p & 1) ? -1.0 : 1.0;
-        {   // Gram column of the candidate: Dp[i] = alpha_i . alpha_p
-            const double part = pair_dot(Al + pp, NPc);
-            if (has_row && h == 0) L.Dp[pi] = part;
+        return ok;
+    };
+    if (warm && warm->fast && warm->n_in < n && !dump) {
+        if (warm->n_in <= 16) fast_done = fast_try(std::integral_constant<int, 16>{});
+        else if (warm->n_in <= 32) fast_done = fast_try(std::integral_constant<int, 32>{});
+    }
+    if (!fast_done) {
+        // ---- P6: alpha = L_G^-1 a for every pair and zt = -L_G^-1 F (column NP): right-looking forward
+        //          substitution over the registers; row l's solution is formed by the lane that owns it, passed to
+        //          its partner, and both update their later rows.
+        {
+            const double dreg = L.invdL[lane < R ? lane : 0];    // lane l: 1 / L[l][l]
+            const double* Lh = L.Lm + h * Nc;                    // row 2 m + h of L starts at Lh + 2 m Nc
+#pragma unroll
+            for (int l = 0; l < R; ++l) {
+                if (l >= Nc) continue;                          // uniform; padding rows have nothing to solve
+                const int ml = l >> 1, hl = l & 1;
+                const double ym = areg[ml] * readlane_d(dreg, l);
+                const double yo = dpp_swap1(ym);
+                const bool mine = h == hl;
+                const double y = mine ? ym : yo;
+                areg[ml] = mine ? y : areg[ml];
+                if (mine && has_col && l < Nc) Al[l * NPc + cc] = y;
+#pragma unroll
+                for (int m = (l + 1) >> 1; m < KH; ++m) {
+                    double coef = Lh[2 * m * Nc + l];
+                    if (2 * m == l) coef = h ? coef : 0.0;       // row 2 m + 0 = l is the pivot row itself
+                    areg[m] = fma(-coef, y, areg[m]);
+                }
+            }
         }
         __syncthreads();
-        const double kpp = L.Dp[pp] + sig2;
-        double lam_p = 0.0;
-        for (;;) {
-            if (++iters > max_iter) { status = 1; break; }
-            const int iq = lane < q ? lane : 0;
-            // l = Lw^-1 kp = M kp,  r = Lw^-T l = M' l   (M lower triangular, zero above the diagonal)
-            g_sync();
-            kpb[lane] = lane < q ? fma(wsgj * sgp, L.Dp[wpj], sig2) : 0.0;
-            g_sync();
-            double lj = 0.0;
-            {
-                const double* mr = Mi + iq * n;
-#pragma unroll 4
-                for (int j = 0; j < q; ++j) lj = fma(mr[j], kpb[j], lj);
+        WIDE_STAMP(5);
+        // ---- P7: slacks s = h + nt . zt_unc (the slack component of zt_unc is zero).  Lane 2 p + h owns row h of pair p.
+        {
+            const double part = pair_dot(Al + NP, NPc);
+            if (has_row) {
+                const double hval = L.hv[row];
+                iscale = 1.0 / (1.0 + fabs(hval));
+                s = hval + (h ? -part : part);
             }
-            if (lane >= q) lj = 0.0;
-            const double dd = kpp - wave_sum(lj * lj);
-            lb[lane] = lj;
-            g_sync();
-            double rj = 0.0;
-            {
-                const double* mc = Mi + iq;
+        }
+        WIDE_STAMP(6);
+        // ---- P8: dual active-set iteration
+        // The factor of G and Gamma move to registers for the duration of the iteration; their LDS becomes the
+        // working set's Gram matrix and inverse factor.
+        constexpr int SAVE_N = (R * R + R * (R + 1) / 2 * NX + WIDE_THREADS - 1) / WIDE_THREADS;
+        const int save_len = R * Nc + Nc * (Nc + 1) / 2 * NX;
+        double saved[SAVE_N];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < SAVE_N; ++i) {
+            const int e = tid + WIDE_THREADS * i;
+            saved[i] = L.Lm[e < save_len ? e : 0];
+        }
+        __syncthreads();
+        for (int e = tid; e < n * n; e += WIDE_THREADS) Mi[e] = 0.0;
+        // Gram matrix of the working set (whole workgroup), its Cholesky factor and M = Lw^-1 (wave 0); false if the
+        // rows are numerically dependent.  Every wave holds the same q, wpj, wsgj.
+        auto rebuild = [&]() -> bool {
+            double* Wsg = reinterpret_cast<double*>(L.Wtab + 2 * ((n + 1) / 2));
+            __syncthreads();               // every wave is done with the old inverse factor
+            if (wave == 0 && lane < q) { L.Wtab[lane] = wpj; Wsg[lane] = wsgj; }
+            __syncthreads();
+            for (int e = tid; e < q * (q + 1) / 2; e += WIDE_THREADS) {
+                int a_ = (int)((__builtin_sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+                while ((a_ + 1) * (a_ + 2) / 2 <= e) ++a_;
+                while (a_ * (a_ + 1) / 2 > e) --a_;
+                const int b_ = e - a_ * (a_ + 1) / 2;
+                const int wa = L.Wtab[a_], wb = L.Wtab[b_];
+                double acc = 0.0;
 #pragma unroll 4
-                for (int i = 0; i < q; ++i) rj = fma(mc[i * n], lb[i], rj);
+                for (int k = 0; k < Nc; ++k) acc = fma(Al[k * NPc + wa], Al[k * NPc + wb], acc);
+                L.Lw[a_ * n + b_] = fma(Wsg[a_] * Wsg[b_], acc, sig2);
             }
-            if (lane >= q) rj = 0.0;
-            double t1 = QP_INF; int kd = 0x7fffffff;
-            if (lane < q && rj > 1e-13) { t1 = lamj / rj; kd = lane; }
-            g_argmin<64>(t1, kd);
-            const bool primal = dd > 1e-12 * kpp && kpp > 0.0;
-            const double t2 = primal ? -sp / dd : QP_INF;
-            const double t = t1 < t2 ? t1 : t2;
-            if (!(t < QP_INF)) { status = 2; break; }
-            if (primal) {
-                // direction in zt coordinates, components k < Nc on lane k (every wave its own copy); the slack
-                // component is sigma (1 - sum r)
+            __syncthreads();
+            if (wave == 0) {
+                const bool ok = chol_rows_lds(L.Lw, q, n, L.invdW);
+                g_sync();
+                if (ok && lane < q) {       // column `lane` of M = Lw^-1 by forward substitution
+                    for (int i = 0; i < q; ++i) {
+                        double x = 0.0;
+                        if (i == lane) x = L.invdW[i];
+                        else if (i > lane) {
+                            double acc = 0.0;
+                            for (int k = lane; k < i; ++k) acc = fma(L.Lw[i * n + k], Mi[k * n + lane], acc);
+                            x = -acc * L.invdW[i];
+                        }
+                        Mi[i * n + lane] = x;
+                    }
+                }
+                if (lane == 0) L.red[13] = ok ? 1.0 : 0.0;
+            }
+            __syncthreads();
+            return L.red[13] != 0.0;
+        };
+        // Warm start: the rows of the controller's previous working set enter together.  With K their Gram matrix,
+        // the minimiser on their intersection has multipliers lambda = -K^-1 s_W (s = slacks at the unconstrained
+        // minimiser); members whose multiplier is not positive are dropped and the rest solved again, until all
+        // are positive - minimiser and set are then a valid state of the dual iteration, which goes on from
+        // there.  A numerically dependent set falls back to the cold start.
+        if (warm && warm->n_in > 0) {
+            q = warm->n_in < n ? warm->n_in : n;
+            {
+                const int rid = lane < q ? (int)warm->in[lane] : 0;
+                wpj = rid >> 1; wsgj = (rid & 1) ? -1.0 : 1.0;
+                if (lane >= q || wpj >= NP) { wpj = 0; wsgj = 1.0; }
+            }
+            if (has_row) L.hv[row] = s;                          // right-hand sides are spent: hv now holds s
+            while (q > 0) {
+                ++iters;
+                if (!rebuild()) { q = 0; break; }
+                const int iq = lane < q ? lane : 0;
+                g_sync();
+                kpb[lane] = lane < q ? L.hv[2 * wpj + (wsgj < 0.0 ? 1 : 0)] : 0.0;
+                g_sync();
+                double lj = 0.0;
+                {
+                    const double* mr = Mi + iq * n;
+#pragma unroll 4
+                    for (int j = 0; j < q; ++j) lj = fma(mr[j], kpb[j], lj);
+                }
+                if (lane >= q) lj = 0.0;
+                lb[lane] = lj;
+                g_sync();
+                double rj = 0.0;
+                {
+                    const double* mc = Mi + iq;
+#pragma unroll 4
+                    for (int i = 0; i < q; ++i) rj = fma(mc[i * n], lb[i], rj);
+                }
+                lamj = lane < q ? -rj : 0.0;
+                const bool keep_me = lane < q && lamj > 0.0;
+                const unsigned long long keep = __ballot(keep_me);
+                const int qn = __popcll(keep);
+                if (qn == q) break;
+                const int pos = __popcll(keep & ((1ull << lane) - 1ull));
+                g_sync();
+                if (keep_me) kpb[pos] = (double)(2 * wpj + (wsgj < 0.0 ? 1 : 0));
+                g_sync();
+                q = qn;
+                const int rid = lane < q ? (int)kpb[lane] : 0;
+                wpj = rid >> 1; wsgj = (rid & 1) ? -1.0 : 1.0; lamj = 0.0;
+            }
+            if (q > 0) {
                 const int kr = lane < Nc ? lane : 0;
                 const double* ak = Al + kr * NPc;
-                double a = sgp * ak[pp];
-                const double rs = rj * wsgj;
+                double a = 0.0;
+                const double ls = lamj * wsgj;
 #pragma unroll 4
-                for (int j = 0; j < q; ++j) a = fma(-ak[__builtin_amdgcn_readlane(wpj, j)], readlane_d(rs, j), a);
-                const double vn = sigma * (1.0 - wave_sum(rj));
+                for (int j = 0; j < q; ++j) a = fma(ak[__builtin_amdgcn_readlane(wpj, j)], readlane_d(ls, j), a);
+                const double lsum = wave_sum(lane < q ? lamj : 0.0);
+                g_sync();
                 avec[lane] = lane < Nc ? a : 0.0;
                 g_sync();
                 const double part = pair_dot(avec, 1);
-                if (has_row) s = fma(t, (h ? -part : part) + sigma * vn, s);
-            }
-            if (lane < q) lamj -= t * rj;
-            lam_p += t;
-            if (primal && t2 <= t1) {          // full step: p joins the working set at position q
-                const double dl = sqrt(dd), idl = 1.0 / dl;
-                if (lane < n) Mi[q * n + lane] = lane < q ? -rj * idl : (lane == q ? idl : 0.0);
-                if (lane == q) { lamj = lam_p; wpj = pp; wsgj = sgp; }
-                if (has_row && row == p) { s = 0.0; inW = true; }
-                ++q;
-                break;
-            }
-            // partial (or dual-only) step: the member at position kd leaves the working set
-            {
-                const int dropped = 2 * __builtin_amdgcn_readlane(wpj, kd) + (readlane_d(wsgj, kd) < 0.0 ? 1 : 0);
-                if (has_row && row == dropped) inW = false;
-                const double lnext = g_next<64>(lamj), snext = g_next<64>(wsgj);
-                const int wnext = g_next_i<64>(wpj);
-                if (lane >= kd && lane < q - 1) { lamj = lnext; wpj = wnext; wsgj = snext; }
-                --q;
-                if (lane >= q) { lamj = 0.0; wpj = 0; wsgj = 1.0; }
-                // rebuild: K_ab = sg_a sg_b alpha_a . alpha_b + 1/rho by the whole workgroup, Lw = chol(K) and
-                // M = Lw^-1 by wave 0
-                if (has_row && row == p) L.red[12] = s;
-                if (!rebuild()) { status = 2; break; }
-                sp = L.red[12];
+                if (has_row) s += (h ? -part : part) + sig2 * lsum;
+                for (int j = 0; j < q; ++j) {
+                    const int rid = 2 * __builtin_amdgcn_readlane(wpj, j) + (readlane_d(wsgj, j) < 0.0 ? 1 : 0);
+                    if (has_row && row == rid) { s = 0.0; inW = true; }
+                }
+            } else {
+                lamj = 0.0; wpj = 0; wsgj = 1.0;
             }
         }
-        if (status) break;
+        WIDE_STAMP(15);
+        for (;;) {
+            double best = QP_INF; int bi = 0x7fffffff;
+            if (has_row && !inW) { best = s * iscale; bi = row; }
+            g_argmin<64>(best, bi);
+            if (has_row && row == bi) L.red[4 + wave] = s;
+            if (lane == 0) { L.red[wave] = best; L.red[8 + wave] = (double)bi; }
+            __syncthreads();
+            double gb = L.red[0], sp = L.red[4]; int p = (int)L.red[8];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const double v = L.red[w]; const int vi = (int)L.red[8 + w];
+                if (v < gb || (v == gb && vi < p)) { gb = v; p = vi; sp = L.red[4 + w]; }
+            }
+            if (!(gb < -1e-10)) break;
+            const int pp = p >> 1;
+            const double sgp = (p & 1) ? -1.0 : 1.0;
+            {   // Gram column of the candidate: Dp[i] = alpha_i . alpha_p
+                const double part = pair_dot(Al + pp, NPc);
+                if (has_row && h == 0) L.Dp[pi] = part;
+            }
+            __syncthreads();
+            const double kpp = L.Dp[pp] + sig2;
+            double lam_p = 0.0;
+            for (;;) {
+                if (++iters > max_iter) { status = 1; break; }
+                const int iq = lane < q ? lane : 0;
+                // l = Lw^-1 kp = M kp,  r = Lw^-T l = M' l   (M lower triangular, zero above the diagonal)
+                g_sync();
+                kpb[lane] = lane < q ? fma(wsgj * sgp, L.Dp[wpj], sig2) : 0.0;
+                g_sync();
+                double lj = 0.0;
+                {
+                    const double* mr = Mi + iq * n;
+#pragma unroll 4
+                    for (int j = 0; j < q; ++j) lj = fma(mr[j], kpb[j], lj);
+                }
+                if (lane >= q) lj = 0.0;
+                const double dd = kpp - wave_sum(lj * lj);
+                lb[lane] = lj;
+                g_sync();
+                double rj = 0.0;
+                {
+                    const double* mc = Mi + iq;
+#pragma unroll 4
+                    for (int i = 0; i < q; ++i) rj = fma(mc[i * n], lb[i], rj);
+                }
+                if (lane >= q) rj = 0.0;
+                double t1 = QP_INF; int kd = 0x7fffffff;
+                if (lane < q && rj > 1e-13) { t1 = lamj / rj; kd = lane; }
+                g_argmin<64>(t1, kd);
+                const bool primal = dd > 1e-12 * kpp && kpp > 0.0;
+                const double t2 = primal ? -sp / dd : QP_INF;
+                const double t = t1 < t2 ? t1 : t2;
+                if (!(t < QP_INF)) { status = 2; break; }
+                if (primal) {
+                    // direction in zt coordinates, components k < Nc on lane k (every wave its own copy); the slack
+                    // component is sigma (1 - sum r)
+                    const int kr = lane < Nc ? lane : 0;
+                    const double* ak = Al + kr * NPc;
+                    double a = sgp * ak[pp];
+                    const double rs = rj * wsgj;
+#pragma unroll 4
+                    for (int j = 0; j < q; ++j) a = fma(-ak[__builtin_amdgcn_readlane(wpj, j)], readlane_d(rs, j), a);
+                    const double vn = sigma * (1.0 - wave_sum(rj));
+                    avec[lane] = lane < Nc ? a : 0.0;
+                    g_sync();
+                    const double part = pair_dot(avec, 1);
+                    if (has_row) s = fma(t, (h ? -part : part) + sigma * vn, s);
+                }
+                if (lane < q) lamj -= t * rj;
+                lam_p += t;
+                if (primal && t2 <= t1) {          // full step: p joins the working set at position q
+                    const double dl = sqrt(dd), idl = 1.0 / dl;
+                    if (lane < n) Mi[q * n + lane] = lane < q ? -rj * idl : (lane == q ? idl : 0.0);
+                    if (lane == q) { lamj = lam_p; wpj = pp; wsgj = sgp; }
+                    if (has_row && row == p) { s = 0.0; inW = true; }
+                    ++q;
+                    break;
+                }
+                // partial (or dual-only) step: the member at position kd leaves the working set
+                {
+                    const int dropped = 2 * __builtin_amdgcn_readlane(wpj, kd) + (readlane_d(wsgj, kd) < 0.0 ? 1 : 0);
+                    if (has_row && row == dropped) inW = false;
+                    const double lnext = g_next<64>(lamj), snext = g_next<64>(wsgj);
+                    const int wnext = g_next_i<64>(wpj);
+                    if (lane >= kd && lane < q - 1) { lamj = lnext; wpj = wnext; wsgj = snext; }
+                    --q;
+                    if (lane >= q) { lamj = 0.0; wpj = 0; wsgj = 1.0; }
+                    // rebuild: K_ab = sg_a sg_b alpha_a . alpha_b + 1/rho by the whole workgroup, Lw = chol(K) and
+                    // M = Lw^-1 by wave 0
+                    if (has_row && row == p) L.red[12] = s;
+                    if (!rebuild()) { status = 2; break; }
+                    sp = L.red[12];
+                }
+            }
+            if (status) break;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < SAVE_N; ++i) {
+            const int e = tid + WIDE_THREADS * i;
+            if (e < save_len) L.Lm[e] = saved[i];
+        }
+        __syncthreads();
+        WIDE_STAMP(7);
+        recover_z();
+    } else {
+        WIDE_STAMP(6); WIDE_STAMP(15); WIDE_STAMP(7);
     }
     if (warm && warm->out && wave == 0) {
         const int qo = status == 0 ? q : 0;
         if (lane < qo) warm->out[lane] = (unsigned char)(2 * wpj + (wsgj < 0.0 ? 1 : 0));
         if (lane == 0) *warm->n_out = qo;
-    }
-    // ---- P9: z from the multipliers: L' z = zt_unc + Nt_W lam; wave 0 solves with column k of L in lane k's
-    //          registers, the slack variable is separate
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < SAVE_N; ++i) {
-        const int e = tid + WIDE_THREADS * i;
-        if (e < save_len) L.Lm[e] = saved[i];
-    }
-    __syncthreads();
-    WIDE_STAMP(7);
-    if (wave == 0) {
-        const int kr = lane < Nc ? lane : 0;
-        double creg[R];
-#pragma unroll
-        for (int i = 0; i < R; ++i) creg[i] = L.Lm[i * Nc + kr];          // L[i][k]; rows >= Nc are zero
-        const double* ak = Al + kr * NPc;
-        double v = ak[NP];
-        const double ls = lamj * wsgj;
-#pragma unroll 4
-        for (int j = 0; j < q; ++j) v = fma(ak[__builtin_amdgcn_readlane(wpj, j)], readlane_d(ls, j), v);
-        if (lane >= Nc) v = 0.0;
-        const double lsum = wave_sum(lane < q ? lamj : 0.0);
-        const double invl = L.invdL[lane < R ? lane : 0];
-        double xres = 0.0;
-#pragma unroll
-        for (int i = R - 1; i >= 0; --i) {
-            const double xv = readlane_d(v, i) * readlane_d(invl, i);     // zero for the padding rows
-            if (lane == i) xres = xv;
-            v = lane < i ? fma(-creg[i], xv, v) : v;
-        }
-        if (lane < Nc) L.usol[lane] = xres;
-        if (lane == 0) L.usol[Nc] = sig2 * lsum;
     }
     __syncthreads();
     WIDE_STAMP(8);
@@ -618,7 +826,7 @@ __device__ __forceinline__ int wide_solve(const MpcConst& c, WideLds& L, double 
     }
     __syncthreads();
     WIDE_STAMP(9);
-    if (st && tid == 0) { st[10] = (unsigned long long)iters; st[11] = __builtin_amdgcn_s_memrealtime() - rt0; }
+    if (st && tid == 0) { st[10] = (unsigned long long)iters | ((unsigned long long)fast_why << 32); st[11] = __builtin_amdgcn_s_memrealtime() - rt0; }
 #undef WIDE_STAMP
     if (iters_out) *iters_out = iters;
     return status;
@@ -682,7 +890,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void mpc_solve_wide_kernel(CtrlDev d,
     // a QP with the same rows; the first pass of a step inherits the last step's set moved one stage forward:
     // input rows u_i -> u_{i-1}, output rows y_j -> y_{j-1} (the new y_0 is a measurement: not carried), and
     // rows of the last stage stay on the last stage as well (the plan's tail is repeated by the shift).
-    WideWarm warm{nullptr, 0, nullptr, nullptr};
+    WideWarm warm{nullptr, 0, nullptr, nullptr, 0};
     if (d.wset) {
         unsigned char* ws = d.wset + (size_t)b * 64;
         unsigned char* wl = reinterpret_cast<unsigned char*>(L.red + 16) + (tid >> 6) * 64;   // this wave's copy
@@ -707,7 +915,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void mpc_solve_wide_kernel(CtrlDev d,
         if (r1 >= 0 && pos1 < 64) wl[pos1] = (unsigned char)r1;
         int tot = c0 + __popcll(m1);
         tot = tot > Nc + 1 ? Nc + 1 : tot;
-        warm.in = wl; warm.n_in = d.warm ? tot : 0; warm.out = ws; warm.n_out = d.wcnt + b;
+        warm.in = wl; warm.n_in = d.warm ? tot : 0; warm.out = ws; warm.n_out = d.wcnt + b; warm.fast = d.warm >= 2;
     }
     __syncthreads();
     int qp_it = 0;
