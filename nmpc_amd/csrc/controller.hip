@@ -231,8 +231,8 @@ static int pick_gs(int Nc) {
 // launch geometry shared by the stand-alone MPC QP and the closed-loop solve kernel
 static int mpc_geom(int Nc, int nx, int mode, int slack, MpcGeom& g) {
     NMPC_REQUIRE(Nc >= 1 && Nc + 1 <= 64, "horizon Nc=%d unsupported (1..63)", Nc);
-    NMPC_REQUIRE(nx >= 2 && nx <= 4, "nx=%d unsupported by the fused MPC kernels (2..4)", nx);
-    g.GS = pick_gs(Nc);
+    NMPC_REQUIRE(nx >= 2 && nx <= 8, "nx=%d unsupported by the fused MPC kernels (2..8)", nx);
+    g.GS = nx > 4 ? 64 : pick_gs(Nc);
     const int n = mpc_nvar(Nc, slack), mt = mpc_nrows(Nc, nx, mode);
     NMPC_REQUIRE(mt <= 4 * 64, "horizon Nc=%d gives %d constraint rows (at most 256)", Nc, mt);
     const size_t per = sizeof(double) * (size_t)mpc_lds_doubles(Nc, nx, n, mt);
@@ -255,6 +255,10 @@ static int dispatch_mpc_qp(const MpcQpArgs& a, const MpcGeom& g, hipStream_t s) 
     if (a.nx == 2) return dispatch_mpc_qp_nx2(a, g, s);
     if (a.nx == 3) return dispatch_mpc_qp_nx3(a, g, s);
     if (a.nx == 4) return dispatch_mpc_qp_nx4(a, g, s);
+    if (a.nx == 5) return dispatch_mpc_qp_nx5(a, g, s);
+    if (a.nx == 6) return dispatch_mpc_qp_nx6(a, g, s);
+    if (a.nx == 7) return dispatch_mpc_qp_nx7(a, g, s);
+    if (a.nx == 8) return dispatch_mpc_qp_nx8(a, g, s);
     set_error("nmpc_mpc_qp: no kernel for nx=%d", a.nx);
     return 1;
 }
@@ -264,6 +268,10 @@ static int dispatch_mpc_solve(const CtrlDev& d, const RunPtrs& rp, int it, int k
     if (d.nx == 2) return dispatch_mpc_solve_nx2(d, rp, it, k, g, s);
     if (d.nx == 3) return dispatch_mpc_solve_nx3(d, rp, it, k, g, s);
     if (d.nx == 4) return dispatch_mpc_solve_nx4(d, rp, it, k, g, s);
+    if (d.nx == 5) return dispatch_mpc_solve_nx5(d, rp, it, k, g, s);
+    if (d.nx == 6) return dispatch_mpc_solve_nx6(d, rp, it, k, g, s);
+    if (d.nx == 7) return dispatch_mpc_solve_nx7(d, rp, it, k, g, s);
+    if (d.nx == 8) return dispatch_mpc_solve_nx8(d, rp, it, k, g, s);
     set_error("nmpc_ctrl_run: no kernel for nx=%d", d.nx);
     return 1;
 }

@@ -25,10 +25,10 @@ namespace nmpc {
 // mpcUtil.py:112-134).  slack = 1: one extra variable with weight rho and coefficient -1 on every row.
 struct MpcConst {
     int Nc, mode, slack;
-    double Q[16];
+    double Q[64];                       // nx * nx, row-major (nx <= 8)
     double R, rho, umin, umax, ymin, ymax, h0;
-    double f0[4];
-    double xmin[4], xmax[4];
+    double f0[8];
+    double xmin[8], xmax[8];
 };
 __host__ __device__ inline int mpc_nvar(int Nc, int slack) { return Nc + (slack ? 1 : 0); }
 __host__ __device__ inline int mpc_nrows(int Nc, int nx, int mode) { return mode ? 2 * (nx + 1) * Nc + 2 * nx : 4 * Nc + 2; }
@@ -282,8 +282,9 @@ struct MpcQpArgs {
     MpcConst c;
 };
 
+// (workgroups have at most four waves; saying so lets the nx > 4 instantiations keep their nx x nx blocks in registers)
 template <int GS, int MPL, int NX, int NC = 0>
-__global__ void mpc_qp_kernel(MpcQpArgs a) {
+__global__ __launch_bounds__(NX > 4 ? 256 : 1024) void mpc_qp_kernel(MpcQpArgs a) {
     extern __shared__ __align__(16) double mpc_lds[];
     const int gpb = blockDim.x / GS, g = threadIdx.x / GS, gl = threadIdx.x % GS;
     const int prob = blockIdx.x * gpb + g;
@@ -358,7 +359,7 @@ struct RunPtrs {
 };
 
 template <int GS, int MPL, int NX, int NC = 0>
-__global__ void mpc_solve_kernel(CtrlDev d, RunPtrs rp, int it, int k) {
+__global__ __launch_bounds__(NX > 4 ? 256 : 1024) void mpc_solve_kernel(CtrlDev d, RunPtrs rp, int it, int k) {
     extern __shared__ __align__(16) double mpc_lds[];
     const int gpb = blockDim.x / GS, g = threadIdx.x / GS, gl = threadIdx.x % GS;
     const int gid = blockIdx.x * gpb + g;
@@ -425,9 +426,17 @@ struct MpcGeom { int GS, gpb, mpl; size_t lds; };
 int dispatch_mpc_qp_nx2(const MpcQpArgs& a, const MpcGeom& g, hipStream_t s);
 int dispatch_mpc_qp_nx3(const MpcQpArgs& a, const MpcGeom& g, hipStream_t s);
 int dispatch_mpc_qp_nx4(const MpcQpArgs& a, const MpcGeom& g, hipStream_t s);
+int dispatch_mpc_qp_nx5(const MpcQpArgs& a, const MpcGeom& g, hipStream_t s);
+int dispatch_mpc_qp_nx6(const MpcQpArgs& a, const MpcGeom& g, hipStream_t s);
+int dispatch_mpc_qp_nx7(const MpcQpArgs& a, const MpcGeom& g, hipStream_t s);
+int dispatch_mpc_qp_nx8(const MpcQpArgs& a, const MpcGeom& g, hipStream_t s);
 int dispatch_mpc_solve_nx2(const CtrlDev& d, const RunPtrs& rp, int it, int k, const MpcGeom& g, hipStream_t s);
 int dispatch_mpc_solve_nx3(const CtrlDev& d, const RunPtrs& rp, int it, int k, const MpcGeom& g, hipStream_t s);
 int dispatch_mpc_solve_nx4(const CtrlDev& d, const RunPtrs& rp, int it, int k, const MpcGeom& g, hipStream_t s);
+int dispatch_mpc_solve_nx5(const CtrlDev& d, const RunPtrs& rp, int it, int k, const MpcGeom& g, hipStream_t s);
+int dispatch_mpc_solve_nx6(const CtrlDev& d, const RunPtrs& rp, int it, int k, const MpcGeom& g, hipStream_t s);
+int dispatch_mpc_solve_nx7(const CtrlDev& d, const RunPtrs& rp, int it, int k, const MpcGeom& g, hipStream_t s);
+int dispatch_mpc_solve_nx8(const CtrlDev& d, const RunPtrs& rp, int it, int k, const MpcGeom& g, hipStream_t s);
 
 template <typename K>
 static int set_lds_attr(K kernel) {
@@ -479,6 +488,23 @@ static int launch_mpc_solve(const CtrlDev& d, const RunPtrs& rp, int it, int k, 
     }                                                                                                              \
     int dispatch_mpc_solve_nx##NX_(const CtrlDev& d, const RunPtrs& rp, int it, int k, const MpcGeom& g, hipStream_t s) { \
         NMPC_GEOM_SWITCH(launch_mpc_solve, NX_, g, d, rp, it, k, g, s)                                             \
+        set_error("nmpc_ctrl_run: no kernel for nx=%d GS=%d rows/lane=%d", d.nx, g.GS, g.mpl);                     \
+        return 1;                                                                                                  \
+    }
+
+// state dimensions 5..8: whole-wave groups only (a 16-lane group has too few registers for the nx x nx blocks)
+#define NMPC_GEOM_SWITCH64(FN, NX_, g, ...)                                       \
+    if (g.GS == 64 && g.mpl <= 1) return FN<64, 1, NX_>(__VA_ARGS__);             \
+    if (g.GS == 64 && g.mpl <= 2) return FN<64, 2, NX_>(__VA_ARGS__);             \
+    if (g.GS == 64 && g.mpl <= 4) return FN<64, 4, NX_>(__VA_ARGS__);
+#define NMPC_DEFINE_MPC_DISPATCH64(NX_)                                                                            \
+    int dispatch_mpc_qp_nx##NX_(const MpcQpArgs& a, const MpcGeom& g, hipStream_t s) {                             \
+        NMPC_GEOM_SWITCH64(launch_mpc_qp, NX_, g, a, g, s)                                                         \
+        set_error("nmpc_mpc_qp: no kernel for nx=%d GS=%d rows/lane=%d", a.nx, g.GS, g.mpl);                       \
+        return 1;                                                                                                  \
+    }                                                                                                              \
+    int dispatch_mpc_solve_nx##NX_(const CtrlDev& d, const RunPtrs& rp, int it, int k, const MpcGeom& g, hipStream_t s) { \
+        NMPC_GEOM_SWITCH64(launch_mpc_solve, NX_, g, d, rp, it, k, g, s)                                           \
         set_error("nmpc_ctrl_run: no kernel for nx=%d GS=%d rows/lane=%d", d.nx, g.GS, g.mpl);                     \
         return 1;                                                                                                  \
     }

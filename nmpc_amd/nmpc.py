@@ -52,9 +52,6 @@ def mpc_qp(list_A, list_B, list_C, x0, y_meas, Xs, Us, f0, h0, Q, R, rho, u_min,
     lA = _f64(list_A); dev = lA.device
     batch = lA.shape[:-2]
     nb = int(np.prod(batch)) if len(batch) else 1
-    if nx > 4:                                   # the fused kernel is built for nx = 2..4
-        return _mpc_qp_composed(lA, list_B, list_C, x0, y_meas, Xs, Us, f0, h0, Q, R, rho, u_min, u_max, y_min, y_max,
-                                Nc, nx, want_matrices)
     lB = _f64(list_B, dev).reshape(batch + (Nc * nx,)); lC = _f64(list_C, dev).reshape(batch + (Nc, nx))
     x0 = _f64(x0, dev).reshape(batch + (nx,)); ym = _f64(y_meas, dev).reshape(batch)
     Xs = _f64(Xs, dev).reshape(batch + (Nc * nx,)); Us = _f64(Us, dev).reshape(batch + (Nc,))
@@ -74,52 +71,6 @@ def mpc_qp(list_A, list_B, list_C, x0, y_meas, Xs, Us, f0, h0, Q, R, rho, u_min,
                                ptr(out.get("Le")), ptr(out.get("h")), ptr(out["u"]), ptr(out["eps"]),
                                ptr(out["xpred"]), ptr(out["status"]), current_stream())
     check(rc, "nmpc_mpc_qp")
-    return out
-
-
-def _mpc_qp_composed(lA, list_B, list_C, x0, y_meas, Xs, Us, f0, h0, Q, R, rho, u_min, u_max, y_min, y_max, Nc, nx,
-                     want_matrices):
-    """The same QP for state dimensions beyond the fused kernel (nx > 4): condensing kernel
-    (nmpc_condense), batched dense products for G, F, L, h, batched QP kernel (nmpc_qp_solve)."""
-    from .mpcutil import getPhi, getGamma, getF0
-    from .qp import solve_qp
-    dev = lA.device
-    batch = lA.shape[:-2]
-    nb = int(np.prod(batch)) if len(batch) else 1
-    lA = lA.reshape(nb, Nc * nx, nx)
-    lB = _f64(list_B, dev).reshape(nb, Nc * nx, 1); lC = _f64(list_C, dev).reshape(nb, Nc, nx)
-    x0 = _f64(x0, dev).reshape(nb, nx, 1); ym = _f64(y_meas, dev).reshape(nb)
-    Xs = _f64(Xs, dev).reshape(nb, Nc * nx, 1); Us = _f64(Us, dev).reshape(nb, Nc, 1)
-    Phi = getPhi(lA, Nc, nx, 1); Gam = getGamma(lA, lB, Nc, nx, 1); F0 = getF0(lA, np.asarray(f0, np.float64).reshape(nx, 1), Nc, nx)
-    Qt = torch.as_tensor(np.asarray(Q, np.float64).reshape(nx, nx), device=dev)
-    Om = torch.kron(torch.eye(Nc, dtype=torch.float64, device=dev), Qt)
-    Rv = float(np.asarray(R).reshape(-1)[0])
-    free = Phi @ x0 + F0                                                   # [nb, Nc*nx, 1]
-    G = 2.0 * (Rv * torch.eye(Nc, dtype=torch.float64, device=dev) + Gam.transpose(1, 2) @ Om @ Gam)
-    F = 2.0 * (Gam.transpose(1, 2) @ Om @ (free - Xs) - Rv * Us)
-    # rows: 4i+{0,1} -/+ u_i, 4i+{2,3} -/+ y_i (y_0 measured, y_i = C_{i-1} x_i + h0), last two -/+ y_Nc
-    mt, n = 4 * Nc + 2, Nc + 1
-    CG = torch.einsum("bir,birk->bik", lC, Gam.reshape(nb, Nc, nx, Nc))     # [nb, Nc, Nc]: C_i Gamma_{i,:}
-    yfree = torch.einsum("bir,bir->bi", lC, free.reshape(nb, Nc, nx)) + float(np.asarray(h0).reshape(-1)[0])
-    Le = torch.zeros(nb, mt, n, dtype=torch.float64, device=dev); hv = torch.zeros(nb, mt, dtype=torch.float64, device=dev)
-    Le[:, :, Nc] = -1.0
-    idx = torch.arange(Nc, device=dev)
-    Le[:, 4 * idx, idx] = -1.0; Le[:, 4 * idx + 1, idx] = 1.0
-    hv[:, 4 * idx] = -float(u_min); hv[:, 4 * idx + 1] = float(u_max)
-    hv[:, 2] = -float(y_min) + ym; hv[:, 3] = float(y_max) - ym
-    rows_m = torch.cat([4 * idx[1:] + 2, torch.tensor([4 * Nc], device=dev)])    # block a+1 of Gamma row-block a
-    Le[:, rows_m, :Nc] = -CG; Le[:, rows_m + 1, :Nc] = CG
-    hv[:, rows_m] = -float(y_min) + yfree; hv[:, rows_m + 1] = float(y_max) - yfree
-    Ge = torch.zeros(nb, n, n, dtype=torch.float64, device=dev); Ge[:, :Nc, :Nc] = G; Ge[:, Nc, Nc] = float(rho)
-    Fe = torch.zeros(nb, n, dtype=torch.float64, device=dev); Fe[:, :Nc] = F[:, :, 0]
-    z, _, status, _ = solve_qp(Ge, Fe, Le, hv, return_info=True)
-    u = z[:, :Nc]
-    xpred = (free + Gam @ u[:, :, None])[:, :, 0]
-    out = dict(u=u.reshape(batch + (Nc,)), eps=z[:, Nc].reshape(batch), xpred=xpred.reshape(batch + (Nc * nx,)),
-               status=status.reshape(batch))
-    if want_matrices:
-        out.update(Ge=Ge.reshape(batch + (n, n)), Fe=Fe.reshape(batch + (n,)), Le=Le.reshape(batch + (mt, n)),
-                   h=hv.reshape(batch + (mt,)))
     return out
 
 

@@ -153,12 +153,14 @@ def test_mpc_qp_vs_oracle(enc, omodel, Nc, ntest):
     os.environ.pop("NMPC_MPC_GS", None)
 
 
-@pytest.mark.parametrize("nx,H,Nc", [(8, 256, 20), (4, 64, 10)])
+@pytest.mark.parametrize("nx,H,Nc", [(8, 256, 20), (4, 64, 10), (5, 100, 12), (6, 64, 30), (7, 128, 8)])
 def test_open_loop_iteration_wide_model(nx, H, Nc):
     """One open-loop LPV iteration of the wide synthetic configuration (nx = 8, nu = ny = 1, H = 256, 20
-    lambda-nodes, Nc = 20; 21 QP variables, 82 rows) and of the shape of the reference's LTI example (nx = 4,
-    H = 64, LTI.ipynb cell 5): embedding on the general-width kernel, condensing kernel, batched products
-    for G, F, L, h, batched QP kernel - against the oracle, plans within 1e-5."""
+    lambda-nodes, Nc = 20; 21 QP variables, 82 rows), of the shape of the reference's LTI example (nx = 4,
+    H = 64, LTI.ipynb cell 5) and of state dimensions in between: embedding on the general-width kernel, then
+    condensing, QP assembly and QP solve in ONE kernel (nmpc_mpc_qp; nothing but nmpc_* calls between the
+    scheduling points and the plan) - against the oracle, plans within 1e-5; with the oracle fed the device's own
+    A, B, C the assembled QP agrees to 1e-12."""
     import nmpc_amd
     from oracle.model import Model
     nu, ny, nb = 1, 1, 6
@@ -192,4 +194,11 @@ def test_open_loop_iteration_wide_model(nx, H, Nc):
         assert np.abs(r["xpred"][i].cpu().numpy() - xpo).max() / np.abs(xpo).max() < 1e-5
         assert rel(r["Le"][i].cpu().numpy(), pc["Le"]) < 1e-5 and rel(r["h"][i].cpu().numpy(), pc["h"]) < 1e-5
         nact += int(np.any(pc["Le"] @ np.append(uo, eo) > pc["h"] - 1e-9))
+        # same inputs: condensing + assembly + solve alone
+        Ad, Bd, Cd = (t[i].double().cpu().numpy() for t in (A, B, C))
+        u2, e2, xp2, pc2 = omq(Ad.reshape(-1, nx), Bd.reshape(-1, 1), Cd.reshape(-1, nx), x0[i], ym[i], Xs[i], Us[i], om.f0, om.h0,
+                               Psi, Om, D, E, M, c, Nc, nx, nu, ny, rho)
+        assert rel(np.tril(r["Ge"][i].cpu().numpy()), np.tril(pc2["Ge"])) < 1e-12 and rel(r["Fe"][i].cpu().numpy(), pc2["Fe"]) < 1e-11
+        assert rel(r["Le"][i].cpu().numpy(), pc2["Le"]) < 1e-12 and rel(r["h"][i].cpu().numpy(), pc2["h"]) < 1e-12
+        assert rel(r["u"][i].cpu().numpy(), u2) < 1e-9 and rel(r["xpred"][i].cpu().numpy(), xp2) < 1e-9
     assert nact >= 2
