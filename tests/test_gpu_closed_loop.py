@@ -72,6 +72,7 @@ def check_parity(orc, out, ctrl, Nsim, traj_tol=1e-4, min_same=0.99, nx=2, targe
     assert np.abs(e_log[:, 0].cpu().numpy() - st("e_log")).max() < traj_tol
     plan, plano = ctrl.logs["plan_log"].cpu().numpy(), st("plan_log")
     same = lpvc.cpu().numpy() == st("lpv_counter")
+    print("pass counts that differ from the oracle's: %.4f of %d (bound %.2f)" % (1.0 - same.mean(), same.size, 1.0 - min_same))
     assert same.mean() > min_same             # a stop test within rounding of tol may flip a pass count
     # plans inside the closed loop are trajectory quantities (they inherit the accumulated state
     # difference): trajectory bar.  The 1e-5 relative bar on plans for IDENTICAL inputs is
@@ -156,7 +157,7 @@ def test_closed_loop_converged_scheduling(enc, omodel):
     noise = 0.014 * np.random.default_rng(3).standard_normal((Nsim, B))
     orc, out, ctrl = run_both(enc, omodel, refs, Nsim, noise=noise, tol=1e-5, max_it=10, sigma=0.014)
     # a 1e-5 stop test sits at the fp32 embedding's own rounding level, so a few pass counts differ
-    check_parity(orc, out, ctrl, Nsim, min_same=0.9)
+    check_parity(orc, out, ctrl, Nsim, min_same=0.95)
     assert out[6].max() > 4
 
 
@@ -213,7 +214,9 @@ def test_closed_loop_long_horizon(enc, omodel):
     st = lambda k: np.stack([o[k] for o in orc])
     assert np.abs(out[8].cpu().numpy() - st("y_log")).max() < 1e-4
     assert np.abs(out[1].cpu().numpy() - st("u_log")).max() < 1e-4
-    assert (out[6].cpu().numpy() == st("lpv_counter")).mean() > 0.9
+    same = out[6].cpu().numpy() == st("lpv_counter")
+    print("pass counts that differ from the oracle's: %.4f of %d" % (1.0 - same.mean(), same.size))
+    assert same.mean() >= 0.97                # stop tolerance 1e-1: far above the kernels' rounding
 
 
 def test_recorded_closed_loop_of_the_reference(enc):

@@ -305,3 +305,45 @@ def test_wide_kernel_on_the_disc_model(enc, omodel, monkeypatch):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_embedding_kernel_variants_on_the_trained_model(omodel, tmp_path):
+    """The three kernels that can serve the disc model - split-fp16 MFMA (default, with and without the stepped
+    layer-1 exponentials), fp32 MFMA (NMPC_EMBED=f32), general-width (NMPC_EMBED=wide) - on the trained weights and
+    the same 40 960 seeded scheduling points (the size of one full pass of the benchmark): each within 1e-6 of the
+    fp64 oracle (lpv_int.py:64-81 lambda_simpson, stages = 20) on every eighth point, and within 2e-6 of each other
+    on all of them, measured per matrix against the size the matrix has over the batch."""
+    import subprocess, sys, os
+    code = ("import sys; sys.path.insert(0, '.'); import numpy as np, torch, nmpc_amd\n"
+            "enc = nmpc_amd.load_system(device='cuda:0'); rng = np.random.default_rng(77); P = 40960\n"
+            "x = rng.uniform(-2.5, 2.5, (P, 2)).astype(np.float32); u = rng.uniform(-2.5, 2.5, (P, 1)).astype(np.float32)\n"
+            "xc = rng.uniform(-2.5, 2.5, (P, 2)).astype(np.float32)\n"
+            "lam, w = nmpc_amd.quad_nodes('simpson', 20)\n"
+            "A, B, C = nmpc_amd.embed(enc, torch.tensor(x), torch.tensor(u), torch.tensor(xc), lam, w)\n"
+            "np.savez(sys.argv[1], x=x, u=u, xc=xc, A=A.cpu().numpy(), B=B.cpu().numpy(), C=C.cpu().numpy())\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    variants = {"split": {}, "split_norecur": {"NMPC_EMBED_RECUR": "0"}, "f32": {"NMPC_EMBED": "f32"}, "wide": {"NMPC_EMBED": "wide"}}
+    out = {}
+    for name, envadd in variants.items():
+        env = {k: v for k, v in os.environ.items() if not k.startswith("NMPC_EMBED")}
+        env.update(envadd)
+        f = str(tmp_path / (name + ".npz"))
+        r = subprocess.run([sys.executable, "-c", code, f], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        out[name] = np.load(f)
+    ref = out["split"]
+    sub = slice(0, None, 8)
+    x, u, xc = (ref[k].astype(np.float64)[sub] for k in ("x", "u", "xc"))
+    Ao, Bo, Co = olpv.embed(omodel, x, u, *olpv.merge_nodes(*olpv.quad_nodes("simpson", 20)), xc=xc)
+    scale = {"A": np.abs(Ao).max(), "B": np.abs(Bo).max(), "C": np.abs(Co).max()}
+    worst = {}
+    for name, d in out.items():
+        for k, o in (("A", Ao), ("B", Bo), ("C", Co)):
+            e = np.abs(d[k].astype(np.float64)[sub].reshape(o.shape) - o).max() / scale[k]
+            worst[(name, k)] = e
+            assert e < 1e-6, (name, k, e)
+    for name, d in out.items():
+        for k in ("A", "B", "C"):
+            e = np.abs(d[k].astype(np.float64) - ref[k].astype(np.float64)).max() / scale[k]
+            assert e < 2e-6, (name, k, e)
+    print("worst error against the oracle per variant:", {n: max(v for (m, _), v in worst.items() if m == n) for n in variants})

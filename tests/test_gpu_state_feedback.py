@@ -73,7 +73,9 @@ def test_par_NMPC_linear_vs_oracle(smodel):
         assert np.abs(x_log[b].cpu().numpy().reshape(Nsim + 1, 2) - o["x_log"]).max() < 1e-4
         assert np.abs(u_log[b].cpu().numpy() - o["u_log"]).max() < 1e-4
         assert np.abs(e_log[b, 0].cpu().numpy() - o["e_log"]).max() < 1e-4
-        assert (lpvc[b].cpu().numpy() == o["lpv_counter"]).mean() > 0.9
+        same = lpvc[b].cpu().numpy() == o["lpv_counter"]
+        print("controller %d: pass counts that differ from the oracle's: %.4f of %d" % (b, 1.0 - same.mean(), same.size))
+        assert same.mean() >= 0.95               # stop tolerance 1e-5 (NMPC.py:609): at the fp32 embedding's rounding level
     assert float(e_log[2].abs().max()) > 1e-3               # the slack was needed for controller 2
     # un-batched call, as the reference makes it
     o1 = nmpc_amd.par_NMPC_linear(plant, enc, xmin, xmax, UMIN, UMAX, [0.0, 0.0], 0, Q, 1.0, 0.1, 0.05, 20, refs[0], Nc=Nc,

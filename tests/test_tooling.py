@@ -4,6 +4,7 @@ import os
 import random
 
 import numpy as np
+import pytest
 
 from conftest import GOLDEN
 
@@ -38,3 +39,28 @@ def test_random_level_reference():
     for b in range(3):
         assert np.array_equal(a[b], random_level_reference(120, [10, 15], [-1, 1], np.random.default_rng(1234 + b)))
     assert nmpc_amd.stackReferences((np.zeros(5), np.ones(5))).shape == (2, 5)
+
+
+def test_hand_placed_wait_states_of_the_embedding_kernels():
+    """The v_fma_mix splits of embed.hip are inline asm, which the compiler's hazard recognizer does not see; an
+    MFMA needs two wait states after a VALU write of an operand.  The checker disassembles every instantiation in
+    the built object; it must itself flag a fabricated violation."""
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import check_hazards
+    fake = ("0000000000001000 <k>:\n"
+            "\tv_fma_mixhi_f16 v12, v3, -1.0, v20 op_sel:[1,0,0] // 000000001000: 00\n"
+            "\ts_nop 0 // 000000001008: 00\n"
+            "\tv_mfma_f32_16x16x32_f16 v[0:3], v[4:7], v[12:15], v[0:3] // 00000000100C: 00\n"
+            "\tv_fma_mixlo_f16 v30, v3, -1.0, v20 // 000000001014: 00\n"
+            "\ts_nop 1 // 000000001018: 00\n"
+            "\tv_mfma_f32_16x16x32_f16 v[0:3], v[4:7], v[28:31], v[0:3] // 00000000101C: 00\n")
+    k, nw, nm, findings = check_hazards.check(fake)
+    assert (k, nw, nm) == (1, 2, 2) and len(findings) == 1 and "v[12:15]" in findings[0]
+    obj = os.path.join(root, "nmpc_amd", "csrc", "build", "embed.o")
+    if not (os.path.exists(obj) and os.path.exists(check_hazards.OBJDUMP)):
+        pytest.skip("embed.o not built here")
+    k, nw, nm, findings = check_hazards.check(check_hazards.disassemble(obj))
+    assert k >= 6 and nw > 100 and nm > 1000          # every instantiation was seen
+    assert not findings, findings[:5]
