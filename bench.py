@@ -361,10 +361,11 @@ def closed_loop_bench(args, cfgname, rank, world, dev, shard):
     sb = solve_bytes_per_controller_pass(NC)
     ach_s = sb * solve_passes / (ms_solve * 1e-3) / 1e9 if n_solve else float("nan")
     roof_solve = {"bound": "hbm", "achieved": ach_s, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_s / HBM_PEAK_GBS,
-                  "traffic": None, "kernel": "mpc_solve_kernel", "launches": n_solve,
+                  "traffic": None, "kernel": "mpc_solve_wide_kernel" if NC >= 24 else "mpc_solve_kernel", "launches": n_solve,
                   "avg_launch_ms": ms_solve / max(n_solve, 1), "bytes_per_controller_pass": sb,
-                  "note": "condense + QP + prediction, one wavefront per controller, everything between A/B/C and the "
-                          "plan stays in LDS/registers: latency-bound, HBM traffic is the algorithmic minimum"}
+                  "note": "condense + QP + prediction, one %s per controller, everything between A/B/C and the "
+                          "plan stays in LDS/registers: latency-bound, HBM traffic is the algorithmic minimum"
+                          % ("workgroup of four wavefronts" if NC >= 24 else "wavefront")}
     dominant_solve = n_solve and ms_solve > ms_embed
     res = {
         "metric": "closed-loop NMPC controller-steps/sec (B=4096, N=10)" if cfgname == "cfg2" else
