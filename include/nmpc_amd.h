@@ -117,7 +117,7 @@ typedef struct nmpc_ctrl_config {
     int batch, Nc, max_iterations, n_sim;
     double tol;                          /* NMPC_test.py:257 */
     double rho;                          /* slack weight, NMPC_test.py:225 */
-    double Q[16];                        /* nx*nx row-major */
+    double Q[64];                        /* nx*nx row-major, nx <= 8 */
     double R;
     double u_min, u_max, y_min, y_max;   /* NORMALISED bounds, NMPC_test.py:70-73 */
     double u0, ustd, y0, ystd;           /* encoder.norm */
@@ -130,7 +130,11 @@ typedef struct nmpc_ctrl_config {
      * is x0, box constraints x_min..x_max (normalised) act on measured and predicted states through
      * getDEMc (mpcUtil.py:112-134), y_min/y_max are unused, the model offset f(0,0) is dropped;
      * hard = 1 removes the slack variable (NMPC_linear's quadprog QP).  x_norm0 / x_normstd: the state
-     * normalisation vectors (norm.y0, norm.ystd of a full-state model). */
+     * normalisation vectors (norm.y0, norm.ystd of a full-state model).
+     * mode 2: the model is its own plant - x+ = f(x, u), y = h(x) + noise, the state is known to the controller
+     * (no observer); otherwise the QP of mode 0.  For models that have no physical plant here (nx up to 8, hidden
+     * width up to 256: the reference's larger encoders, LTI.ipynb cell 5, sinCos.ipynb cell 6, and the synthetic wide
+     * configuration); x_log holds the model state, y_log / y_est_log the noisy / noise-free output. */
     int mode, hard;
     double x_min[4], x_max[4];
     double x_norm0[4], x_normstd[4];

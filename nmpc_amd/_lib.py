@@ -71,7 +71,7 @@ class CtrlConfig(ctypes.Structure):
     """struct nmpc_ctrl_config of include/nmpc_amd.h"""
     _fields_ = [("batch", ctypes.c_int), ("Nc", ctypes.c_int), ("max_iterations", ctypes.c_int),
                 ("n_sim", ctypes.c_int), ("tol", ctypes.c_double), ("rho", ctypes.c_double),
-                ("Q", ctypes.c_double * 16), ("R", ctypes.c_double),
+                ("Q", ctypes.c_double * 64), ("R", ctypes.c_double),
                 ("u_min", ctypes.c_double), ("u_max", ctypes.c_double), ("y_min", ctypes.c_double),
                 ("y_max", ctypes.c_double), ("u0", ctypes.c_double), ("ustd", ctypes.c_double),
                 ("y0", ctypes.c_double), ("ystd", ctypes.c_double), ("dt", ctypes.c_double),

@@ -93,6 +93,7 @@ struct ModelDev {
     float* enc;     // observer net, plain row-major params concatenated (may be null):
                     // lin_w[out,in] lin_b w0[H,in] b0 w2[H,H] b2 w4[out,H] b4 w2^T[H,H]
     float* hplain;  // h-net in the same plain layout (for the output estimate)
+    float* fplain;  // f-net in the same plain layout (the model as its own plant)
     double f0[16];  // f(0,0)  ("correction",   NMPC_test.py:38)
     double h0[16];  // h(0)    ("correction_h", NMPC_test.py:41)
 };

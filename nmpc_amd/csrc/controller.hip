@@ -145,6 +145,108 @@ __global__ __launch_bounds__(64 * PLANT_WAVES) void plant_kernel(CtrlDev d, RunP
     }
 }
 
+// plain-layout net evaluated by one workgroup of 256 threads in fp64 (fp32 weights), hidden width H <= 256: thread k
+// owns hidden unit k; `in` (nin values), t1s, t2s (H doubles each) and out (nout <= 8) live in LDS.
+__device__ void block_mlp(const float* __restrict__ p, int nin, int nout, int H, const double* in, double* t1s, double* t2s,
+                          double* out) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* lin_w = p; const float* lin_b = lin_w + nout * nin;
+    const float* w0 = lin_b + nout; const float* b0 = w0 + H * nin;
+    const float* w2 = b0 + H; const float* b2 = w2 + H * H;
+    const float* w4 = b2 + H; const float* b4 = w4 + nout * H;
+    const float* w2t = b4 + nout;
+    if (tid < H) {
+        double a = b0[tid];
+        for (int j = 0; j < nin; ++j) a += (double)w0[tid * nin + j] * in[j];
+        t1s[tid] = tanh(a);
+    }
+    __syncthreads();
+    if (tid < H) {
+        double a = b2[tid];
+#pragma unroll 8
+        for (int k = 0; k < H; ++k) a += (double)w2t[k * H + tid] * t1s[k];
+        t2s[tid] = tanh(a);
+    }
+    __syncthreads();
+    for (int c = wave; c < nout; c += 4) {
+        double part = 0.0;
+        for (int k = lane; k < H; k += 64) part += (double)w4[c * H + k] * t2s[k];
+        double v = wave_sum(part);
+        v += (double)lin_b[c] + (double)b4[c];
+        for (int j = 0; j < nin; ++j) v += (double)lin_w[c * nin + j] * in[j];
+        if (lane == 0) out[c] = v;
+    }
+    __syncthreads();
+}
+
+// The model as its own plant (no counterpart among the reference's plants, which are ODEs of the disc: Systems.py;
+// used for models of other systems, whose plants are not part of the hot path): x+ = f(x, u) and y = h(x+) evaluated
+// with the model's nets in fp64, measurement noise added to y, the state handed to the controller as it is.  One
+// workgroup per controller; logs, warm-start shift and next scheduling points as in plant_kernel.
+template <int NX>
+__global__ __launch_bounds__(256) void plant_model_kernel(CtrlDev d, RunPtrs rp, int k) {
+    __shared__ double in[16], outv[8], t1s[256], t2s[256];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    if (b == 0 && tid == 0)
+        for (int it = 1; it <= d.maxit; ++it) d.nact[it] = 0;
+    const int Nc = d.Nc, H = d.hidden, ns = d.n_sim;
+    double* up = d.uplan + (size_t)b * Nc;
+    double* xpd = d.xpred + (size_t)b * Nc * NX;
+    const double u_n = up[0];
+    if (tid < NX) in[tid] = d.x0n[(size_t)b * NX + tid];
+    if (tid == NX) in[NX] = u_n;
+    __syncthreads();
+    block_mlp(d.fplain, NX + 1, NX, H, in, t1s, t2s, outv);
+    double xn[NX];
+#pragma unroll
+    for (int r = 0; r < NX; ++r) xn[r] = outv[r];
+    __syncthreads();
+    if (tid < NX) in[tid] = outv[tid];
+    __syncthreads();
+    block_mlp(d.hplain, NX, 1, H, in, t1s, t2s, outv);
+    const double yhat = outv[0];
+    const double y = d.ystd * yhat + d.y0 + (rp.noise ? rp.noise[(size_t)k * rp.noise_ld + b] : 0.0);
+    const double yn = (y - d.y0) / d.ystd;
+    // everything that is shifted is read before anything is written
+    const int e = tid;
+    const bool one = e < Nc * NX;
+    const double xold = one ? xpd[e] : 0.0;
+    const double xsh = one ? xpd[e + NX < Nc * NX ? e + NX : e] : 0.0;
+    const double upv = e < Nc ? up[e] : 0.0;
+    const double upn = e < Nc ? up[e + 1 < Nc ? e + 1 : Nc - 1] : 0.0;
+    const double epsv = d.eps[b];
+    const int cntv = d.cnt[b];
+    __syncthreads();
+    if (tid == 0) {
+        d.ymeas[b] = yn;
+        if (rp.y_log) rp.y_log[(size_t)b * (ns + 1) + k + 1] = y;
+        if (rp.y_est_log) rp.y_est_log[(size_t)b * (ns + 1) + k + 1] = d.ystd * yhat + d.y0;
+        if (rp.u_log) rp.u_log[(size_t)b * ns + k] = d.ustd * u_n + d.u0;
+        if (rp.e_log) rp.e_log[(size_t)b * ns + k] = epsv;
+        if (rp.lpv_counter) rp.lpv_counter[(size_t)b * ns + k] = cntv;
+    }
+    if (tid < NX) {
+        double v = 0.0;
+#pragma unroll
+        for (int r = 0; r < NX; ++r) if (r == tid) v = xn[r];
+        if (rp.x_log) rp.x_log[((size_t)b * (ns + 1) + k + 1) * NX + tid] = v;
+        d.x0n[(size_t)b * NX + tid] = v;
+    }
+    if (e < Nc) {
+        if (rp.plan_log) rp.plan_log[((size_t)b * ns + k) * Nc + e] = upv;
+        up[e] = upn;
+        d.us32[(size_t)b * Nc + e] = (float)upn;
+    }
+    if (one) {
+        xpd[e] = xsh;
+        d.xc32[(size_t)b * Nc * NX + e] = (float)xsh;
+        double sv = xold;                 // x_k of the next first pass: x_0 = new state, x_k = shifted prediction k-1
+#pragma unroll
+        for (int r = 0; r < NX; ++r) if (r == e) sv = xn[r];
+        d.xs32[(size_t)b * Nc * NX + e] = (float)sv;
+    }
+}
+
 // State-feedback step (NMPC.py:484-495, 628-640): plant RK4, the measured state (plus noise
 // [n_sim, batch, NX]) becomes x0, logs, warm-start shift.  One thread per controller; the disc
 // plant has two states, so NX = 2.
@@ -194,15 +296,17 @@ __global__ void plant_state_kernel(CtrlDev d, RunPtrs rp, int k) {
     for (int e = 0; e < Nc * NX; ++e) d.xs32[(size_t)b * Nc * NX + e] = e < NX ? (float)x0n[e] : (float)xpd[e - NX];
 }
 
+struct State8 { double v[8]; };
+
 template <int NX>
-__global__ void reset_kernel(CtrlDev d, double u0n, double x0a, double x0b, double x0c, double x0d, double pw, double pth) {
+__global__ void reset_kernel(CtrlDev d, double u0n, State8 x0s, double pw, double pth) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b == 0) {
         for (int i = 0; i < (d.maxit + 2) * MAX_SLICES; ++i) d.nact[i] = 0;
         *d.qp_fail = 0ull;
     }
     if (b >= d.B) return;
-    const double x0[4] = {x0a, x0b, x0c, x0d};
+    const double* x0 = x0s.v;
     const int Nc = d.Nc;
     for (int r = 0; r < NX; ++r) d.x0n[(size_t)b * NX + r] = x0[r];
     for (int e = 0; e < Nc * NX; ++e) {
@@ -355,16 +459,18 @@ extern "C" int nmpc_ctrl_create(nmpc_ctrl** out, const nmpc_model* m, const nmpc
     NMPC_REQUIRE(on_device(m->device), "nmpc_ctrl_create: the model lives on device %d, which is not the current device", m->device);
     NMPC_REQUIRE(m->d.nu == 1 && m->d.ny == 1, "nmpc_ctrl_create: closed loop needs nu = ny = 1 (as the reference)");
     const int mode = cfg->mode;
-    NMPC_REQUIRE(mode == 0 || mode == 1, "nmpc_ctrl_create: mode %d unknown (0 output feedback, 1 state feedback)", mode);
-    NMPC_REQUIRE(mode == 1 || (m->d.enc && m->d.hplain && m->d.n_enc_in <= MAX_HIST), "nmpc_ctrl_create: model has no observer net");
-    NMPC_REQUIRE(mode == 0 || m->d.nx == 2, "nmpc_ctrl_create: state feedback drives the two-state disc plant (nx = 2)");
-    NMPC_REQUIRE(cfg->Nc * m->d.nx <= 128, "nmpc_ctrl_create: Nc*nx=%d exceeds 128", cfg->Nc * m->d.nx);
+    NMPC_REQUIRE(mode >= 0 && mode <= 2, "nmpc_ctrl_create: mode %d unknown (0 output feedback, 1 state feedback, 2 model as plant)", mode);
+    NMPC_REQUIRE(mode != 0 || (m->d.enc && m->d.hplain && m->d.n_enc_in <= MAX_HIST), "nmpc_ctrl_create: model has no observer net");
+    NMPC_REQUIRE(mode != 0 || m->d.nx <= 4, "nmpc_ctrl_create: the observer loop supports nx = 2..4 (model has nx = %d)", m->d.nx);
+    NMPC_REQUIRE(mode != 1 || m->d.nx == 2, "nmpc_ctrl_create: state feedback drives the two-state disc plant (nx = 2)");
+    NMPC_REQUIRE(mode != 2 || (m->d.fplain && m->d.hplain), "nmpc_ctrl_create: the model-as-plant loop needs nets with two hidden layers, nu = ny = 1");
+    NMPC_REQUIRE(cfg->Nc * m->d.nx <= (mode == 2 ? 256 : 128), "nmpc_ctrl_create: Nc*nx=%d exceeds %d", cfg->Nc * m->d.nx, mode == 2 ? 256 : 128);
     NMPC_REQUIRE(cfg->batch >= 1 && cfg->max_iterations >= 1 && cfg->max_iterations <= 64 && cfg->n_sim >= 1,
                  "nmpc_ctrl_create: bad batch/max_iterations/n_sim");
     NMPC_REQUIRE(cfg->n_nodes >= 1 && cfg->n_nodes <= NMPC_MAX_NODES, "nmpc_ctrl_create: bad node count");
     nmpc_ctrl* c = new nmpc_ctrl();
     const int slack = (mode == 1 && cfg->hard) ? 0 : 1;
-    if (mpc_geom(cfg->Nc, m->d.nx, mode, slack, c->g)) { delete c; return 1; }
+    if (mpc_geom(cfg->Nc, m->d.nx, mode == 1 ? 1 : 0, slack, c->g)) { delete c; return 1; }
     c->m = m->d;
     NMPC_HIP_CHECK(hipGetDevice(&c->device));
     CtrlDev& d = c->d;
@@ -372,10 +478,11 @@ extern "C" int nmpc_ctrl_create(nmpc_ctrl** out, const nmpc_model* m, const nmpc
     const int B = cfg->batch, Nc = cfg->Nc, nx = m->d.nx;
     d.B = B; d.Nc = Nc; d.nx = nx; d.maxit = cfg->max_iterations; d.n_sim = cfg->n_sim;
     d.n_enc_in = mode ? 1 : m->d.n_enc_in;
+    d.plant_mode = mode; d.hidden = m->d.hidden;
     // observer histories (NMPC_test.py:115-118): n_uhist past inputs then n_yhist past outputs feed the encoder
     // net; 0/0 in the config means the symmetric split nb = na, outputs = na + 1
     d.na = cfg->n_uhist; d.nyh = cfg->n_yhist;
-    if (mode == 1) { d.na = 0; d.nyh = 1; }
+    if (mode != 0) { d.na = 0; d.nyh = 1; }
     else if (d.na == 0 && d.nyh == 0) { d.na = (d.n_enc_in - 1) / 2; d.nyh = d.n_enc_in - d.na; }
     if (mode == 0 && (d.na < 0 || d.nyh < 1 || d.na + d.nyh != d.n_enc_in)) {
         set_error("nmpc_ctrl_create: n_uhist=%d + n_yhist=%d does not match the observer net's %d inputs", d.na, d.nyh, d.n_enc_in);
@@ -390,7 +497,7 @@ extern "C" int nmpc_ctrl_create(nmpc_ctrl** out, const nmpc_model* m, const nmpc
     }
     d.u0 = cfg->u0; d.ustd = cfg->ustd; d.y0 = cfg->y0; d.ystd = cfg->ystd; d.dt = cfg->dt;
     for (int i = 0; i < 6; ++i) d.plant[i] = cfg->plant[i];
-    d.enc = m->d.enc; d.hplain = m->d.hplain;
+    d.enc = m->d.enc; d.hplain = m->d.hplain; d.fplain = m->d.fplain;
     {   // the node table every embedding launch of this controller uses, prepared once
         NodeTable raw;
         raw.n = cfg->n_nodes;
@@ -484,14 +591,17 @@ extern "C" void nmpc_ctrl_destroy(nmpc_ctrl* c) {
 extern "C" int nmpc_ctrl_reset(nmpc_ctrl* c, const double* x0n, double u0n, const double* plant_x0, void* stream) {
     NMPC_REQUIRE(c && x0n, "nmpc_ctrl_reset: null argument");
     NMPC_REQUIRE(on_device(c->device), "nmpc_ctrl_reset: the controllers live on device %d, which is not the current device", c->device);
-    double x0[4] = {0, 0, 0, 0};
-    for (int r = 0; r < c->d.nx; ++r) x0[r] = x0n[r];
+    State8 x0{};
+    for (int r = 0; r < c->d.nx; ++r) x0.v[r] = x0n[r];
     const double pw = plant_x0 ? plant_x0[0] : 0.0, pth = plant_x0 ? plant_x0[1] : 0.0;
     const int threads = 128, grid = (c->d.B + threads - 1) / threads;
-    if (c->d.nx == 2) hipLaunchKernelGGL((reset_kernel<2>), dim3(grid), dim3(threads), 0, (hipStream_t)stream, c->d, u0n, x0[0], x0[1], x0[2], x0[3], pw, pth);
-    else if (c->d.nx == 3) hipLaunchKernelGGL((reset_kernel<3>), dim3(grid), dim3(threads), 0, (hipStream_t)stream, c->d, u0n, x0[0], x0[1], x0[2], x0[3], pw, pth);
-    else if (c->d.nx == 4) hipLaunchKernelGGL((reset_kernel<4>), dim3(grid), dim3(threads), 0, (hipStream_t)stream, c->d, u0n, x0[0], x0[1], x0[2], x0[3], pw, pth);
-    else { set_error("nmpc_ctrl_reset: nx=%d unsupported", c->d.nx); return 1; }
+    hipStream_t st = (hipStream_t)stream;
+    switch (c->d.nx) {
+#define NMPC_RESET_CASE(NX_) case NX_: hipLaunchKernelGGL((reset_kernel<NX_>), dim3(grid), dim3(threads), 0, st, c->d, u0n, x0, pw, pth); break;
+        NMPC_RESET_CASE(2) NMPC_RESET_CASE(3) NMPC_RESET_CASE(4) NMPC_RESET_CASE(5) NMPC_RESET_CASE(6) NMPC_RESET_CASE(7) NMPC_RESET_CASE(8)
+#undef NMPC_RESET_CASE
+        default: set_error("nmpc_ctrl_reset: nx=%d unsupported", c->d.nx); return 1;
+    }
     NMPC_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -514,7 +624,7 @@ extern "C" int nmpc_ctrl_run(nmpc_ctrl* c, int k0, int nsteps, const double* Xs,
         const CtrlDev& d = sl.d;
         const size_t o = (size_t)sl.b0;
         RunPtrs rp{};
-        rp.Xs = Xs + o * ntot * nx; rp.Us = Us + o * ntot; rp.noise = noise ? noise + o * (c->d.c.mode ? nx : 1) : nullptr; rp.noise_ld = c->d.B;
+        rp.Xs = Xs + o * ntot * nx; rp.Us = Us + o * ntot; rp.noise = noise ? noise + o * (c->d.plant_mode == 1 ? nx : 1) : nullptr; rp.noise_ld = c->d.B;
         rp.x_log = x_log ? x_log + o * (ns + 1) * nx : nullptr; rp.u_log = u_log ? u_log + o * ns : nullptr;
         rp.e_log = e_log ? e_log + o * ns : nullptr; rp.y_log = y_log ? y_log + o * (ns + 1) : nullptr;
         rp.y_est_log = y_est_log ? y_est_log + o * (ns + 1) : nullptr;
@@ -550,7 +660,15 @@ extern "C" int nmpc_ctrl_run(nmpc_ctrl* c, int k0, int nsteps, const double* Xs,
             ProfRec pr;
             const bool on = prof_begin(c, 2, k, s, pr);
             const int threads = 64 * PLANT_WAVES, grid = (d.B + PLANT_WAVES - 1) / PLANT_WAVES;
-            if (d.c.mode == 1) hipLaunchKernelGGL((plant_state_kernel<2>), dim3((d.B + 127) / 128), dim3(128), 0, s, d, rp, k);
+            if (d.plant_mode == 2) {
+                switch (d.nx) {
+#define NMPC_PM_CASE(NX_) case NX_: hipLaunchKernelGGL((plant_model_kernel<NX_>), dim3(d.B), dim3(256), 0, s, d, rp, k); break;
+                    NMPC_PM_CASE(2) NMPC_PM_CASE(3) NMPC_PM_CASE(4) NMPC_PM_CASE(5) NMPC_PM_CASE(6) NMPC_PM_CASE(7) NMPC_PM_CASE(8)
+#undef NMPC_PM_CASE
+                    default: set_error("nmpc_ctrl_run: nx=%d unsupported", d.nx); return 1;
+                }
+            }
+            else if (d.c.mode == 1) hipLaunchKernelGGL((plant_state_kernel<2>), dim3((d.B + 127) / 128), dim3(128), 0, s, d, rp, k);
             else if (d.nx == 2) hipLaunchKernelGGL((plant_kernel<2>), dim3(grid), dim3(threads), 0, s, d, rp, k);
             else if (d.nx == 3) hipLaunchKernelGGL((plant_kernel<3>), dim3(grid), dim3(threads), 0, s, d, rp, k);
             else if (d.nx == 4) hipLaunchKernelGGL((plant_kernel<4>), dim3(grid), dim3(threads), 0, s, d, rp, k);

@@ -281,10 +281,11 @@ static int model_fill(nmpc_model* m, int nx, int nu, int ny, int hidden, int Lf,
         return 0;
     };
     NMPC_REQUIRE(!enc || loop_ok, "nmpc_model_create: an observer net needs hidden = 64, two hidden layers, nu = ny = 1, nx = 2..4");
-    if (loop_ok) {
+    if (Lf == 2 && Lh == 2 && nu == 1 && ny == 1) {      // closed loops: output estimate; the model as its own plant
         if (upload_plain(hn, nx, ny, &m->d.hplain)) return 1;
-        if (enc && upload_plain(enc, n_enc_in, nx, &m->d.enc)) return 1;
+        if (upload_plain(fn, nx + nu, nx, &m->d.fplain)) return 1;
     }
+    if (loop_ok && enc && upload_plain(enc, n_enc_in, nx, &m->d.enc)) return 1;
     if (!narrow) {           // no 64-wide packs: the general-width kernel serves the embedding
         return 0;
     }
@@ -343,6 +344,7 @@ extern "C" void nmpc_model_destroy(nmpc_model* m) {
     if (m->d.hpack_h2) (void)hipFree(m->d.hpack_h2);
     if (m->d.enc) (void)hipFree(m->d.enc);
     if (m->d.hplain) (void)hipFree(m->d.hplain);
+    if (m->d.fplain) (void)hipFree(m->d.fplain);
     if (m->d.wide_slab) (void)hipFree(m->d.wide_slab);
     delete m;
 }

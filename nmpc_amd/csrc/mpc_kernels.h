@@ -340,8 +340,9 @@ struct CtrlDev {
     unsigned* qp_stat;             // [B][2]: solves, active-set iterations per controller
     // fp32 scheduling points and embedding outputs
     float *xs32, *us32, *xc32, *A32, *B32, *C32;
-    const float *enc, *hplain;
-    int n_enc_in;
+    const float *enc, *hplain, *fplain;
+    int n_enc_in, hidden;
+    int plant_mode;   // 0 disc ODE + observer, 1 disc ODE with measured state, 2 the model as its own plant
     // long-horizon kernels: final working set of each controller's last QP solve (row ids, 64 per controller) and
     // its size; null when the working set is not carried over
     unsigned char* wset;

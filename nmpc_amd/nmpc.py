@@ -45,6 +45,24 @@ class NoisyUnbalancedDisc(OutputUnbalancedDisc):
         super().__init__(dt, sigma_n, seed)
 
 
+class ModelPlant:
+    """The model as its own plant: x+ = f(x, u), y = h(x) + N(0, sigma_n), the state known to the controller (no
+    observer).  For models whose physical plant is not part of this package (state dimensions up to 8, hidden
+    width up to 256); pass it where the reference's scripts pass their deepSI system."""
+
+    def __init__(self, dt=0.1, sigma_n=(0,), seed=0):
+        self.dt = float(dt)
+        self.sigma_n = list(sigma_n)
+        self.seed = int(seed)
+        self.x0 = None
+
+    def reset_state(self):
+        self.x0 = None
+
+    def params(self):
+        return [0.0] * 6
+
+
 def mpc_qp(list_A, list_B, list_C, x0, y_meas, Xs, Us, f0, h0, Q, R, rho, u_min, u_max, y_min, y_max, Nc, nx,
            want_matrices=False):
     """One condensed QP of the output-constrained controller (NMPC_test.py:206-238), batched.
@@ -81,8 +99,10 @@ class Controller:
                  nodes, weights, tol=1e-1, rho=1000.0, state_feedback=None):
         """state_feedback: None for the output-feedback controller, or a dict(x_min, x_max [nx] normalised
         state bounds, y0, ystd [nx] state normalisation, hard=bool) for the state-feedback controllers."""
-        if encoder.nx not in (2, 3, 4):
-            raise _lib.NmpcError("closed-loop controllers support nx = 2..4 (model has nx = %d)" % encoder.nx)
+        model_plant = isinstance(system, ModelPlant)
+        if encoder.nx not in ((2, 3, 4, 5, 6, 7, 8) if model_plant else (2, 3, 4)):
+            raise _lib.NmpcError("closed-loop controllers support nx = 2..4, with the model as plant 2..8 (model has nx = %d)"
+                                 % encoder.nx)
         cfg = _lib.CtrlConfig()
         cfg.batch, cfg.Nc, cfg.max_iterations, cfg.n_sim = int(batch), int(Nc), int(max_iterations), int(Nsim)
         cfg.tol, cfg.rho = float(tol), float(rho)
@@ -103,7 +123,9 @@ class Controller:
         for i in range(len(nodes)):
             cfg.lam[i] = float(nodes[i]); cfg.w[i] = float(weights[i])
         self.state_feedback = state_feedback is not None
-        if state_feedback is None:           # NMPC_test.py:115-118: uhist has encoder.na entries, yhist encoder.nb + 1
+        if model_plant:
+            cfg.mode = 2
+        elif state_feedback is None:         # NMPC_test.py:115-118: uhist has encoder.na entries, yhist encoder.nb + 1
             cfg.n_uhist, cfg.n_yhist = int(encoder.na), int(encoder.nb) + 1
         if state_feedback is not None:
             cfg.mode, cfg.hard = 1, int(bool(state_feedback.get("hard", False)))

@@ -103,11 +103,14 @@ def mpc_qp(list_A, list_B, list_C, x0, y_meas, Xs, Us, f0, h0, Psi, Omega, D, E,
 def output_nmpc_linear(model, u_min, u_max, y_min, y_max, x0, Q, R, dt, stages, y_reference_list,
                        Nc=5, Nsim=30, max_iterations=1, tol=1e-1, rho=1000.0, noise=None,
                        rule="simpson", dlam=None, targets=None, plant_x0=None, merge=True, target_as_executed=True,
-                       embed_fn=None, timers=None):
+                       embed_fn=None, timers=None, plant="disc"):
     """Closed loop of the output-constrained LPV-NMPC with observer, single controller.
 
     noise: optional array [Nsim] added to the measured angle (sigma_n of the plant).
     embed_fn: alternative to lpv.embed with the same signature (lpv.embed_functorch).
+    plant: "disc" (the reference's plant with the observer in the loop) or "model": the model is its own plant,
+    x+ = f(x, u), y = h(x) + noise, and the controller is handed the state (no observer) - the closed loop of
+    models whose physical plant is not part of the hot path (noise is then in physical output units).
     timers: optional float array [Nsim, 4] that receives per-step seconds in the reference's buckets
     (NMPC_test.py:152-300): getAB (embedding), solve (condensing + QP + prediction), overhead, sim (plant).
     Returns a dict of logs named as the reference's return tuple (NMPC_test.py:320).
@@ -169,14 +172,21 @@ def output_nmpc_linear(model, u_min, u_max, y_min, y_max, x0, Q, R, dt, stages, 
         plan_log[k] = u
         u_den = model.ustd * u[0] + model.u0
         t0 = time.perf_counter()
-        xp = disc_step(xp, u_den, dt)
-        t_sim = time.perf_counter() - t0
-        y_meas = xp[1] + (0.0 if noise is None else noise[k])
-        y_meas_n = np.atleast_1d((y_meas - model.y0) / model.ystd)
-        uhist = np.append(uhist[1:], u[0])
-        yhist = np.append(yhist[1:], y_meas_n[0])
-        zest = model.encoder(uhist, yhist)
-        yest = model.h(zest)
+        if plant == "model":
+            zest = model.f(x0n, u[:nu])
+            yest = model.h(zest)
+            t_sim = time.perf_counter() - t0
+            y_meas = model.ystd * yest[0] + model.y0 + (0.0 if noise is None else noise[k])
+            y_meas_n = np.atleast_1d((y_meas - model.y0) / model.ystd)
+        else:
+            xp = disc_step(xp, u_den, dt)
+            t_sim = time.perf_counter() - t0
+            y_meas = xp[1] + (0.0 if noise is None else noise[k])
+            y_meas_n = np.atleast_1d((y_meas - model.y0) / model.ystd)
+            uhist = np.append(uhist[1:], u[0])
+            yhist = np.append(yhist[1:], y_meas_n[0])
+            zest = model.encoder(uhist, yhist)
+            yest = model.h(zest)
         x_log[k + 1] = zest; y_log[k + 1] = y_meas
         y_est_log[k + 1] = model.ystd * yest[0] + model.y0
         u_log[k] = u_den; e_log[k] = eps

@@ -302,6 +302,63 @@ def test_closed_loop_larger_state_models(omodel, nx):
     assert np.median(np.abs(y[:, 1:] - refs[:, :Nsim])) < 0.1        # the loop still tracks
 
 
+@pytest.mark.parametrize("nx,H,Nc,trained", [(2, 64, 10, True), (8, 256, 20, False), (5, 100, 12, False), (4, 64, 30, True)])
+def test_closed_loop_model_as_plant(omodel, nx, H, Nc, trained):
+    """Closed loops for state dimensions up to 8 (hidden width up to 256; Nc = 30 runs the long-horizon kernels):
+    the model is its own plant (x+ = f(x, u), y = h(x) + noise, state handed to the controller), so the whole
+    step - embedding, condensing + QP, plant - stays on the device for models beyond the disc's.  Regulation to
+    given targets from a random initial state with input and output bounds that become active; trajectories
+    against the oracle at the 1e-4 bar."""
+    import nmpc_amd
+    from oracle.model import Model
+    if trained:
+        om = omodel if nx == 2 else padded_disc_model(omodel, extra=nx - 2)      # extra weakly coupled states
+        params = {k: [np.asarray(a, np.float32) for a in n.params()] for k, n in (("fn", om.fn), ("hn", om.hn))}
+        enc = nmpc_amd.Encoder(params, norm=nmpc_amd.Norm(om.u0, om.ustd, om.y0, om.ystd), device="cuda:0")
+        ub, ylo, yhi, xscale, Rw = 3.0, -0.8, 0.8, 0.6, 1.0
+    else:
+        om = Model.synthetic(nx, 1, 1, H, seed=5)
+        om.fn.lin_w = (0.5 * om.fn.lin_w).astype(np.float32).astype(np.float64)      # a contraction: the loop stays bounded
+        om = Model(om.fn, om.hn, None)
+        params = {k: [np.asarray(a, np.float32) for a in n.params()] for k, n in (("fn", om.fn), ("hn", om.hn))}
+        enc = nmpc_amd.Encoder(params, device="cuda:0")
+        ub, ylo, yhi, xscale, Rw = 1.0, -2.0, 1.0, 0.3, 10.0     # the nets' outputs sit near h(0) ~ 0.7: the upper bound bites
+    Nsim, B = 25, 5
+    rng = np.random.default_rng(21)
+    Q = np.diag(rng.uniform(1, 10, nx))
+    Xs = np.zeros((B, nx, Nsim + Nc)); Us = np.zeros((B, 1, Nsim + Nc))
+    Xs[:, :, Nsim // 2:] = 0.05 * rng.standard_normal((B, nx, 1))                  # the targets move once
+    noise = 0.005 * rng.standard_normal((Nsim, B))
+    x0s = xscale * rng.standard_normal((B, nx))
+    refs = np.zeros((B, Nsim + Nc))
+    st = {k: [] for k in ("y_log", "u_log", "x_log", "lpv_counter", "e_log")}
+    outs = []
+    for b in range(B):
+        o = output_nmpc_linear(om, -ub, ub, [ylo], [yhi], x0s[b], Q, Rw, 0.1, 20, refs[b], Nc=Nc, Nsim=Nsim, max_iterations=4,
+                               tol=1e-2, noise=noise[:, b], targets=(Xs[b], Us[b]), plant="model")
+        for k in st:
+            st[k].append(o[k])
+        # one batched run per initial state would hide nothing: the batch runs together below
+    got = []
+    plant = nmpc_amd.ModelPlant(dt=0.1, sigma_n=[0.005])
+    for b in range(B):          # x0 is a scalar argument of the reference's signature: one call per initial state
+        out = nmpc_amd.output_NMPC_linear(plant, enc, -ub, ub, [ylo], [yhi], x0s[b], Q, Rw, 0.1, 0.05, 20, refs[b:b + 1], Nc=Nc,
+                                          Nsim=Nsim, max_iterations=4, tol=1e-2, noise=noise[:, b:b + 1],
+                                          targets=(torch.tensor(Xs[b:b + 1]), torch.tensor(Us[b:b + 1])))
+        got.append(out)
+    for b in range(B):
+        out = got[b]
+        y, u, x, cnt, e = (out[i].cpu().numpy() for i in (8, 1, 0, 6, 2))
+        assert np.abs(y.reshape(-1) - st["y_log"][b]).max() < 1e-4
+        assert np.abs(u.reshape(-1) - st["u_log"][b]).max() < 1e-4
+        assert np.abs(x.reshape(Nsim + 1, nx) - st["x_log"][b]).max() < 1e-4
+        assert np.abs(e.reshape(nx, Nsim)[0] - st["e_log"][b]).max() < 1e-4
+        assert (cnt.reshape(-1) == st["lpv_counter"][b]).mean() >= 0.9
+    allu = np.stack(st["u_log"]); ally = np.stack(st["y_log"])
+    if trained or nx == 8:      # in these scenarios the bounds are reached
+        assert (np.abs(allu) > 0.98 * ub - 1e-9).any() or (ally > 0.95 * yhi).any()
+
+
 def test_recorded_long_runs_of_the_reference(enc):
     """Experiments/lpv_counter_tight.npy and lpv_counter_noise.npy of the reference: LPV passes per step of
     two 4950-step runs on references/randomLevelTime25_30Range-1_1Nsim5000.npy whose exact settings are
