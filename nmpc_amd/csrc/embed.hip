@@ -330,6 +330,31 @@ __device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, fl
             rho[s] = __builtin_amdgcn_exp2f(fminf(fmaxf(-dl * g[s], -64.0f), 64.0f));
         }
     }
+    // The matrix products of a node are NG = 8 (1 + NOUT) groups of three MFMAs on one pair of weight
+    // fragments (high and low plane): forward groups in the order (T, ks), reverse groups in the order
+    // (c, T, ks).  The fragments are loop invariant and sit at fixed LDS addresses, so the pair of group
+    // i + PF is read while group i multiplies (a ring of RING register slots, carried over the node
+    // boundary and over the activation phases); sched_barrier fences keep the groups in this order.
+    constexpr int NG = 8 * (1 + NOUT), RING = NOUT <= 2 ? 4 : 2, PF = RING - 1;
+    static_assert(NG % RING == 0, "ring position must repeat from node to node");
+    f16x8 fh[RING], fl[RING];
+    auto frag_read = [&](int i, int lo_) {           // i: group index within a node (compile-time after unrolling)
+        if (i < 8) {
+            const int T = i >> 1, ks = i & 1;
+            fh[i % RING] = WF[((0 * 4 + T) * 2 + ks) * 64 + lo_];
+            fl[i % RING] = WF[((1 * 4 + T) * 2 + ks) * 64 + lo_];
+        } else {
+            const int j = i - 8, c = j >> 3, T = (j >> 1) & 3, ks = j & 1;
+            fh[i % RING] = WR[c * 1024 + ((0 * 4 + T) * 2 + ks) * 64 + lo_];
+            fl[i % RING] = WR[c * 1024 + ((1 * 4 + T) * 2 + ks) * 64 + lo_];
+        }
+    };
+    {
+        int lo = lane;
+        asm volatile("" : "+v"(lo));
+#pragma unroll
+        for (int i = 0; i < PF; ++i) frag_read(i, lo);
+    }
     for (int node = n0; node < n1; ++node) {
         const float lam = nt.lam[node];
         const float wn = nt.w[node];
@@ -342,7 +367,7 @@ __device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, fl
             wcur = wn;
         }
         int lo = lane;
-        asm volatile("" : "+v"(lo));
+        asm volatile("" : "+v"(lo));               // keeps the fragment reads inside the loop
         float r1[16], wd1[16];                     // r1 = (1 + t1) / 2 is the operand of the forward product
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
@@ -357,16 +382,15 @@ __device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, fl
         split16(r1, BH, BL);
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
         f32x4 acc[4];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int T = 0; T < 4; ++T) {
-                const f16x8 ah = WF[((0 * 4 + T) * 2 + ks) * 64 + lo];
-                const f16x8 al = WF[((1 * 4 + T) * 2 + ks) * 64 + lo];
-                acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, BH[ks], ks == 0 ? b2[T] : acc[T], 0, 0, 0);
-                acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, BL[ks], acc[T], 0, 0, 0);
-                acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, BH[ks], acc[T], 0, 0, 0);
-            }
+        for (int i = 0; i < 8; ++i) {              // forward: W2 r1
+            const int T = i >> 1, ks = i & 1;
+            acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[i % RING], BH[ks], ks == 0 ? b2[T] : acc[T], 0, 0, 0);
+            acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[i % RING], BL[ks], acc[T], 0, 0, 0);
+            acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[i % RING], BH[ks], acc[T], 0, 0, 0);
+            frag_read(i + PF, lo);
+            __builtin_amdgcn_sched_barrier(0);
         }
         float d2q[16];                             // (1 - t2^2) / 4
 #pragma unroll
@@ -375,21 +399,25 @@ __device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, fl
             d2q[s] = fmaf(-r, r, r);
         }
         split16(d2q, BH, BL);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int c = 0; c < NOUT; ++c) {
+        for (int j = 0; j < 8 * NOUT; ++j) {       // reverse: ((4 W4[c]) o W2)^T d2, then q[c] += d1 o (.)
+            const int i = 8 + j, T = (j >> 1) & 3, ks = j & 1;
+            acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[i % RING], BH[ks], ks == 0 ? zero4 : acc[T], 0, 0, 0);
+            acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[i % RING], BL[ks], acc[T], 0, 0, 0);
+            acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[i % RING], BH[ks], acc[T], 0, 0, 0);
+            frag_read((i + PF) % NG, lo);          // the last PF reads are the next node's first forward groups
+            if (ks == 1 && j >= 3) {               // the tile that finished two groups ago
+                const int jp = j - 2, cp = jp >> 3, Tp = (jp >> 1) & 3;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-                for (int T = 0; T < 4; ++T) {
-                    const f16x8 ah = WR[c * 1024 + ((0 * 4 + T) * 2 + ks) * 64 + lo];
-                    const f16x8 al = WR[c * 1024 + ((1 * 4 + T) * 2 + ks) * 64 + lo];
-                    acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, BH[ks], ks == 0 ? zero4 : acc[T], 0, 0, 0);
-                    acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, BL[ks], acc[T], 0, 0, 0);
-                    acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, BH[ks], acc[T], 0, 0, 0);
-                }
+                for (int r = 0; r < 4; ++r) q[cp][4 * Tp + r] = fmaf(acc[Tp][r], wd1[4 * Tp + r], q[cp][4 * Tp + r]);
             }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+            constexpr int jp = 8 * NOUT - 1, cp = jp >> 3, Tp = (jp >> 1) & 3;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) q[c][s] = fmaf(acc[s >> 2][s & 3], wd1[s], q[c][s]);
+            for (int r = 0; r < 4; ++r) q[cp][4 * Tp + r] = fmaf(acc[Tp][r], wd1[4 * Tp + r], q[cp][4 * Tp + r]);
         }
     }
 
