@@ -372,7 +372,7 @@ __device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, fl
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             float e;
-            if constexpr (RECUR) { e = e1[s]; e1[s] = e * rho[s]; }
+            if constexpr (RECUR) e = e1[s];        // stepped to the next node inside the reverse groups below
             else e = __builtin_amdgcn_exp2f(-fmaf(lam, g[s], b0[s]));
             const float r = __builtin_amdgcn_rcpf(1.0f + e);
             r1[s] = r;
@@ -407,6 +407,8 @@ __device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, fl
             acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[i % RING], BL[ks], acc[T], 0, 0, 0);
             acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[i % RING], BH[ks], acc[T], 0, 0, 0);
             frag_read((i + PF) % NG, lo);          // the last PF reads are the next node's first forward groups
+            if constexpr (RECUR)                   // in place, long after 1 + e was formed: no register copies
+                if (j < 8) { e1[2 * j] *= rho[2 * j]; e1[2 * j + 1] *= rho[2 * j + 1]; }
             if (ks == 1 && j >= 3) {               // the tile that finished two groups ago
                 const int jp = j - 2, cp = jp >> 3, Tp = (jp >> 1) & 3;
 #pragma unroll
