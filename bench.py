@@ -474,11 +474,14 @@ def wide_bench(args, rank, world, dev, shard):
                      + (2 * H * nx + 2 * H * H + 2 * ny * H * H + 2 * ny * H * nx))
     te = float(np.median(emb_ms))
     ach = B * Nc * flops_pt / (te * 1e-3) / 1e12
+    f32_wide = os.environ.get("NMPC_EMBED_WIDE") == "f32"      # diagnostic switch: the exact-fp32 streaming kernel
+    peak = FP32_MFMA_PEAK_TFLOPS if f32_wide else FP16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS
     return {
         "metric": "open-loop LPV-NMPC controller-iterations/sec (cfg5: nx=8, hidden 256, N=20, %d controllers)" % int(tot_ctrl),
         "value": tot_ctrl * K / (region_max[0] * 1e-3), "unit": "controller-iterations/s", "n_gpus": world, "steps": K,
         "warmup": W, "ms_per_step": region_max[0] / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32 MFMA (embedding) + f64 (condensing, QP)", "data": "synthetic",
+        "dtype": ("f32 MFMA (embedding) + f64 (condensing, QP)" if f32_wide else
+                  "f32 via split-f16 MFMA, f32 accumulate (embedding) + f64 (condensing, QP)"), "data": "synthetic",
         "config": {"workload": "cfg5: synthetic nets nx=8 nu=ny=1 hidden 256 (weights N(0,1/fan_in), seed 0), 20 lambda nodes, "
                                "Nc=20, one open-loop iteration = embedding + condensing + QP assembly + QP on random points; "
                                "%d controllers on this rank of %d" % (B, int(tot_ctrl)),
@@ -486,10 +489,12 @@ def wide_bench(args, rank, world, dev, shard):
                    "parallelism": "dp%d (independent shards)" % world},
         "n_ranks_seen": int(round(n_ranks_seen)), "ms_per_step_repeats": [m / K for m in region_max],
         "qp_status_nonzero": int(tot_fail), "gathered_rows": int(gathered["u"].shape[0]),
-        "roofline": {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "embed_wide_kernel",
+        "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                     "frac": ach / peak, "traffic": None, "kernel": "embed_wide_kernel" if f32_wide else "embed_panel_kernel",
                      "avg_launch_ms": te, "flops_per_launch": B * Nc * flops_pt,
-                     "peak_note": "exact-f32 MFMA (v_mfma_f32_16x16x4_f32) peak"},
+                     "launch_note": "one embedding call = two launches (f net, h net), event-timed together",
+                     "peak_note": ("exact-f32 MFMA (v_mfma_f32_16x16x4_f32) peak" if f32_wide else
+                                   "dense f16 MFMA peak (16 x 157.3) / 3 products per f32 product; achieved = algorithmic f32 flops")},
     }
 
 

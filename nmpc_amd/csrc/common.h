@@ -78,6 +78,25 @@ struct WideNet {
     int layers;         // hidden layers (mpcUtil.py:7,18-25: CasADiExp loops over f_n_hidden_layers); 2 = embed_wide.hip, else embed_deep.hip
 };
 
+// One net in the layout of embed_panel.hip.  Units are numbered by MFMA position: element j (0..7) that lane
+// group g = lane >> 4 supplies to k-step ks (32 units) is unit 16 (2 ks + (j >> 2)) + 4 g + (j & 3), which is
+// also row 4 g + (j & 3) of the 16-row output tile 2 ks + (j >> 2): an accumulator pair is the next B operand.
+struct PanelNet {
+    const _Float16* fwd;   // [HT][KST][2 planes][64][8]  s_f 2 c2 W2   rows = units of tile T, K = units of k-step
+    const _Float16* rev;   // [HT][KST][2][64][8]          s_r W2^T
+    const _Float16* w0t;   // [KST][2][64][8]              s_0 W0^T      rows = inputs (16, zero padded)
+    const float* w0g;      // [H][16]   c2 W0 rows (slopes of the layer-1 exponents)
+    const float* cb0;      // [H]       c2 b0
+    const float* cb2s;     // [H]       256 s_f c2 (b2 - W2 1)   (the forward operand is 256 r1)
+    const float* w4s;      // [nout_pad][H]  s_c W4[c]
+    const float* oscale;   // [nout_pad]     16 / (s_0 s_v s_r s_c)
+    const float* lin;      // [nout_pad][16] W_lin
+    const float* j0;       // [nout_pad][16] nonlinear-branch Jacobian at the origin
+    float inv_sf, s_v;     // 1 / (256 s_f); scale of the contraction operand
+    int ht, nout_pad;
+    int ok;                // 0: this net does not suit the format (the fp32 kernel serves it)
+};
+
 // Device-resident packed networks.
 struct ModelDev {
     int nx, nu, ny, hidden, n_enc_in;
@@ -88,6 +107,8 @@ struct ModelDev {
     float* hpack_h2;   // h-net, split-fp16 MFMA layout
     WideNet wide_f, wide_h;   // both nets for the general-width kernel
     float* wide_slab;         // their storage
+    PanelNet panel_f, panel_h;   // split-fp16 layout of the wide kernel (two hidden layers, width 65..256); .ok = 0 if absent
+    float* panel_slab;
     int narrow_ok;            // the 64-wide kernels cover this model's sizes
     int step_ok;              // layer-1 biases small enough for node-to-node stepping of 2^-a (embed.hip)
     float* enc;     // observer net, plain row-major params concatenated (may be null):

@@ -17,6 +17,10 @@
 #include "common.h"
 #include "embed.h"
 #include "embed_wide.h"
+#include "embed_panel.h"
+
+#include <cstdlib>
+#include <cstring>
 
 namespace nmpc {
 
@@ -186,6 +190,25 @@ static int wide_launch_net(const WideNet& net, WideArgs a, const NodeTable& nt, 
     return 1;
 }
 
+// NMPC_EMBED_WIDE=f32 keeps nets of width 128 / 256 on the exact-fp32 kernel of this file (diagnostic);
+// otherwise they run on the split-fp16 kernel of embed_panel.hip when their weights suit it
+static bool panel_enabled() {
+    static std::atomic<int> v{-1};
+    int r = v.load(std::memory_order_relaxed);
+    if (r < 0) { const char* e = getenv("NMPC_EMBED_WIDE"); r = (e && !strcmp(e, "f32")) ? 0 : 1; v.store(r, std::memory_order_relaxed); }
+    return r == 1;
+}
+
+static int wide_or_panel(const WideNet& wn, const PanelNet& pn, const WideArgs& a, const NodeTable& nt, hipStream_t s, bool loop) {
+    if (pn.ok && panel_enabled()) {
+        PanelArgs p{};
+        p.pa = a.pa; p.pb = a.pb; p.oa = a.oa; p.ob = a.ob; p.na = a.na; p.nb = a.nb; p.nout = a.nout;
+        p.npts = a.npts; p.count_dev = a.count_dev; p.act = a.act; p.group = a.group;
+        return panel_launch_net(pn, p, nt, s, loop);
+    }
+    return wide_launch_net(wn, a, nt, s, loop);
+}
+
 // nt: nodes with lambda = 0 already moved into w_zero (embed_launch)
 int embed_wide_launch(const ModelDev& m, const EmbedArgs& e, const NodeTable& nt, hipStream_t s, bool loop) {
     const bool do_f = e.x && e.u && e.A && e.B, do_h = e.xc && e.C;
@@ -193,11 +216,11 @@ int embed_wide_launch(const ModelDev& m, const EmbedArgs& e, const NodeTable& nt
     a.npts = e.npts; a.count_dev = e.count_dev; a.act = e.act; a.group = e.group < 1 ? 1 : e.group;
     if (do_f) {
         a.pa = e.x; a.pb = e.u; a.oa = e.A; a.ob = e.B; a.na = m.nx; a.nb = m.nu; a.nout = m.nx;
-        if (wide_launch_net(m.wide_f, a, nt, s, loop)) return 1;
+        if (wide_or_panel(m.wide_f, m.panel_f, a, nt, s, loop)) return 1;
     }
     if (do_h) {
         a.pa = e.xc; a.pb = nullptr; a.oa = e.C; a.ob = nullptr; a.na = m.nx; a.nb = 0; a.nout = m.ny;
-        if (wide_launch_net(m.wide_h, a, nt, s, loop)) return 1;
+        if (wide_or_panel(m.wide_h, m.panel_h, a, nt, s, loop)) return 1;
     }
     return 0;
 }

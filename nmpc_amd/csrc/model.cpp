@@ -207,6 +207,83 @@ static void pack_wide(const float* const* p, int L, int n_in, int n_out, int hid
         }
 }
 
+// Layout of the split-fp16 wide kernel (embed_panel.hip; PanelNet in embed_panel.h).  Appends to `slab` (floats;
+// fragment regions hold two halves per float) and records offsets in `off` (fwd, rev, w0t, w0g, cb0, cb2s, w4s,
+// oscale).  Returns false when the net does not suit the format (non-finite or all-zero matrices).
+static bool pack_panel(const float* const* p, int n_in, int n_out, int hidden, int ht, int nout_pad,
+                       std::vector<float>& slab, size_t off[8], float* inv_sf, float* s_v_out) {
+    const float *w0 = p[2], *b0 = p[3], *w2 = p[4], *b2 = p[5], *w4 = p[6];
+    const double c2 = 2.0 * 1.4426950408889634074;
+    const int H = 16 * ht, kst = ht / 2;
+    auto grab = [&](size_t nfl) { const size_t o = slab.size(); slab.resize(o + ((nfl + 3) & ~(size_t)3), 0.0f); return o; };
+    off[0] = grab((size_t)ht * kst * 512); off[1] = grab((size_t)ht * kst * 512); off[2] = grab((size_t)kst * 512);
+    off[3] = grab((size_t)H * 16); off[4] = grab(H); off[5] = grab(H); off[6] = grab((size_t)nout_pad * H); off[7] = grab(nout_pad);
+    auto W2 = [&](int i, int k) { return (i < hidden && k < hidden) ? (double)w2[(size_t)i * hidden + k] : 0.0; };
+    auto W0 = [&](int k, int j) { return (k < hidden && j < n_in) ? (double)w0[(size_t)k * n_in + j] : 0.0; };
+    auto W4 = [&](int c, int k) { return (c < n_out && k < hidden) ? (double)w4[(size_t)c * hidden + k] : 0.0; };
+    // power of two that brings mx into [lo, 2 lo)
+    auto pow2_to = [](double mx, double lo) { int e = 0; std::frexp(mx / lo, &e); return std::ldexp(1.0, 1 - e); };
+    double m2 = 0.0, m0 = 0.0;
+    bool ok = true;
+    for (int i = 0; i < hidden; ++i)
+        for (int k = 0; k < hidden; ++k) { const double v = std::fabs(W2(i, k)); if (!std::isfinite(v)) ok = false; m2 = std::fmax(m2, v); }
+    for (int k = 0; k < hidden; ++k)
+        for (int j = 0; j < n_in; ++j) { const double v = std::fabs(W0(k, j)); if (!std::isfinite(v)) ok = false; m0 = std::fmax(m0, v); }
+    for (int k = 0; k < hidden; ++k) if (!std::isfinite((double)b0[k]) || !std::isfinite((double)b2[k])) ok = false;
+    if (!ok || !(m2 > 0.0) || !(m0 > 0.0)) return false;
+    const double s_f = pow2_to(2.0 * c2 * m2, 512.0), s_r = pow2_to(m2, 512.0), s_0 = pow2_to(m0, 512.0);
+    std::vector<double> s_c(nout_pad, 1.0);
+    for (int c = 0; c < n_out; ++c) {
+        double mx = 0.0;
+        for (int k = 0; k < hidden; ++k) { const double v = std::fabs(W4(c, k)); if (!std::isfinite(v)) return false; mx = std::fmax(mx, v); }
+        if (mx > 0.0) s_c[c] = pow2_to(mx, 128.0);
+    }
+    // |s_r W2^T (d2 o s_c W4[c])| d1 <= bound with d1, d2 <= 1/4: s_v brings the bound to 2^10 at most
+    double bound = 0.0;
+    for (int c = 0; c < n_out; ++c)
+        for (int k = 0; k < hidden; ++k) {
+            double a = 0.0;
+            for (int j = 0; j < hidden; ++j) a += std::fabs(W2(j, k)) * 0.25 * s_c[c] * std::fabs(W4(c, j));
+            bound = std::fmax(bound, 0.25 * s_r * a);
+        }
+    double s_v = 1.0;
+    if (bound > 0.0) { int e = 0; std::frexp(bound, &e); s_v = std::ldexp(1.0, 10 - e); }
+    const double s_b = 256.0;                          // the kernel forms 256 r1 as the forward operand
+    *inv_sf = (float)(1.0 / (s_f * s_b));
+    *s_v_out = (float)s_v;
+    _Float16* fwd = reinterpret_cast<_Float16*>(slab.data() + off[0]);
+    _Float16* rev = reinterpret_cast<_Float16*>(slab.data() + off[1]);
+    _Float16* w0t = reinterpret_cast<_Float16*>(slab.data() + off[2]);
+    auto put = [&](_Float16* reg, size_t frag, int lane, int j, double w) {
+        if (!(std::fabs(w) < 6.0e4)) ok = false;
+        const _Float16 h = (_Float16)(float)w;
+        const _Float16 l = (_Float16)(float)(w - (double)(float)h);
+        reg[((frag * 2 + 0) * 64 + lane) * 8 + j] = h;
+        reg[((frag * 2 + 1) * 64 + lane) * 8 + j] = l;
+    };
+    for (int ks = 0; ks < kst; ++ks)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+                const int g = lane >> 4, r = lane & 15;
+                const int k = 16 * (2 * ks + (j >> 2)) + 4 * g + (j & 3);       // unit of K element j
+                for (int T = 0; T < ht; ++T) {
+                    put(fwd, (size_t)T * kst + ks, lane, j, s_f * 2.0 * c2 * W2(16 * T + r, k));
+                    put(rev, (size_t)T * kst + ks, lane, j, s_r * W2(k, 16 * T + r));
+                }
+                put(w0t, ks, lane, j, s_0 * W0(k, r));
+            }
+    for (int k = 0; k < hidden; ++k) {
+        for (int j = 0; j < n_in; ++j) slab[off[3] + (size_t)k * 16 + j] = (float)(c2 * W0(k, j));
+        slab[off[4] + k] = (float)(c2 * (double)b0[k]);
+        double a = b2[k];
+        for (int i = 0; i < hidden; ++i) a -= W2(k, i);
+        slab[off[5] + k] = (float)(s_f * s_b * c2 * a);
+        for (int c = 0; c < n_out; ++c) slab[off[6] + (size_t)c * H + k] = (float)(s_c[c] * W4(c, k));
+    }
+    for (int c = 0; c < nout_pad; ++c) slab[off[7] + c] = (float)(16.0 / (s_0 * s_v * s_r * s_c[c]));
+    return ok;
+}
+
 static void eval_net_at_zero(const float* const* p, int L, int n_out, int hidden, double* y) {
     std::vector<double> t(hidden), tn(hidden);
     for (int k = 0; k < hidden; ++k) t[k] = std::tanh((double)p[3][k]);
@@ -265,6 +342,25 @@ static int model_fill(nmpc_model* m, int nx, int nu, int ny, int hidden, int Lf,
             w.w4s = b + o[6]; w.lin = b + o[7]; w.j0 = b + o[8]; w.ht = ht; w.nout_pad = nout_pad; w.layers = layers;
         };
         bind(m->d.wide_f, of, padout(nx), Lf); bind(m->d.wide_h, oh, padout(ny), Lh);
+        // split-fp16 layout of the wide kernel for two-hidden-layer nets of width 65..256 (embed_panel.hip)
+        if (ht >= 8 && Lf == 2 && Lh == 2) {
+            std::vector<float> ps;
+            size_t pf[8], ph[8];
+            float isf_f = 1.f, sv_f = 1.f, isf_h = 1.f, sv_h = 1.f;
+            const bool okf = pack_panel(fn, nx + nu, nx, hidden, ht, padout(nx), ps, pf, &isf_f, &sv_f);
+            const bool okh = pack_panel(hn, nx, ny, hidden, ht, padout(ny), ps, ph, &isf_h, &sv_h);
+            NMPC_HIP_CHECK(hipMalloc(&m->d.panel_slab, ps.size() * sizeof(float)));
+            NMPC_HIP_CHECK(hipMemcpy(m->d.panel_slab, ps.data(), ps.size() * sizeof(float), hipMemcpyHostToDevice));
+            auto pbind = [&](PanelNet& w, const WideNet& wn, const size_t* o, int nout_pad, float isf, float sv, bool ok) {
+                const float* b = m->d.panel_slab;
+                w.fwd = reinterpret_cast<const _Float16*>(b + o[0]); w.rev = reinterpret_cast<const _Float16*>(b + o[1]);
+                w.w0t = reinterpret_cast<const _Float16*>(b + o[2]); w.w0g = b + o[3]; w.cb0 = b + o[4]; w.cb2s = b + o[5];
+                w.w4s = b + o[6]; w.oscale = b + o[7]; w.lin = wn.lin; w.j0 = wn.j0; w.inv_sf = isf; w.s_v = sv;
+                w.ht = ht; w.nout_pad = nout_pad; w.ok = ok ? 1 : 0;
+            };
+            pbind(m->d.panel_f, m->d.wide_f, pf, padout(nx), isf_f, sv_f, okf);
+            pbind(m->d.panel_h, m->d.wide_h, ph, padout(ny), isf_h, sv_h, okh);
+        }
     }
     eval_net_at_zero(fn, Lf, nx, hidden, m->d.f0);
     eval_net_at_zero(hn, Lh, ny, hidden, m->d.h0);
@@ -346,6 +442,7 @@ extern "C" void nmpc_model_destroy(nmpc_model* m) {
     if (m->d.hplain) (void)hipFree(m->d.hplain);
     if (m->d.fplain) (void)hipFree(m->d.fplain);
     if (m->d.wide_slab) (void)hipFree(m->d.wide_slab);
+    if (m->d.panel_slab) (void)hipFree(m->d.panel_slab);
     delete m;
 }
 

@@ -222,8 +222,9 @@ def test_ablist_family_on_golden(enc, golden):
 @pytest.mark.parametrize("nx,nu,ny,H", [(4, 1, 1, 64), (8, 1, 3, 64), (3, 2, 2, 128), (8, 1, 1, 256), (5, 1, 2, 100)])
 def test_wide_nets(nx, nu, ny, H):
     """Nets beyond the 64-wide kernels (deepSI encoders with nx = 4 and 8: LTI.ipynb cell 5, sinCos.ipynb
-    cell 6; the synthetic nx = 8 / H = 256 configuration) run on the general-width kernel: exact-fp32
-    MFMA with weight fragments streamed from L2.  H = 100 exercises the zero padding of hidden units."""
+    cell 6; the synthetic nx = 8 / H = 256 configuration) run on the general-width kernels: exact-fp32 MFMA with
+    weight fragments streamed from L2 for widths up to 64, the split-fp16 panel kernel above that.  H = 100
+    exercises the zero padding of hidden units."""
     import nmpc_amd
     from oracle.model import Model
     om = Model.synthetic(nx, nu, ny, H, seed=3)
@@ -305,6 +306,47 @@ def test_wide_kernel_on_the_disc_model(enc, omodel, monkeypatch):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("nx,nu,ny,H", [(8, 1, 1, 256), (3, 2, 2, 128), (5, 1, 2, 100), (8, 1, 3, 256)])
+def test_wide_kernel_variants(nx, nu, ny, H, tmp_path):
+    """Nets of hidden width 65..256 run on the split-fp16 panel kernel (three fp16 MFMA products per fp32 product,
+    activations shared through LDS) unless NMPC_EMBED_WIDE=f32 keeps them on the exact-fp32 streaming kernel: both
+    within 2e-6 of the fp64 oracle and of each other on 1000 points (ragged against the 16-, 32- and 64-point
+    workgroups), relative to the size each matrix has over the batch; 1e-5 is the bar (lpv_int.py:64-81)."""
+    import subprocess, sys, os
+    code = ("import sys; sys.path.insert(0, '.'); import numpy as np, torch, nmpc_amd\n"
+            "from oracle.model import Model\n"
+            "nx, nu, ny, H = %d, %d, %d, %d\n"
+            "om = Model.synthetic(nx, nu, ny, H, seed=5)\n"
+            "params = {k: [np.asarray(a, np.float32) for a in n.params()] for k, n in (('fn', om.fn), ('hn', om.hn))}\n"
+            "enc = nmpc_amd.Encoder(params, device='cuda:0'); rng = np.random.default_rng(21); P = 1000\n"
+            "x = rng.uniform(-2, 2, (P, nx)).astype(np.float32); u = rng.uniform(-2, 2, (P, nu)).astype(np.float32)\n"
+            "xc = rng.uniform(-2, 2, (P, nx)).astype(np.float32)\n"
+            "lam, w = nmpc_amd.quad_nodes('simpson', 10)\n"
+            "A, B, C = nmpc_amd.embed(enc, torch.tensor(x), torch.tensor(u), torch.tensor(xc), lam, w)\n"
+            "np.savez(sys.argv[1], x=x, u=u, xc=xc, A=A.cpu().numpy(), B=B.cpu().numpy(), C=C.cpu().numpy())\n" % (nx, nu, ny, H))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for name, envadd in (("panel", {}), ("f32", {"NMPC_EMBED_WIDE": "f32"})):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("NMPC_EMBED")}
+        env.update(envadd)
+        f = str(tmp_path / (name + ".npz"))
+        r = subprocess.run([sys.executable, "-c", code, f], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        out[name] = np.load(f)
+    from oracle.model import Model
+    om = Model.synthetic(nx, nu, ny, H, seed=5)
+    d = out["panel"]
+    Ao, Bo, Co = olpv.embed(om, d["x"].astype(np.float64), d["u"].astype(np.float64),
+                            *olpv.merge_nodes(*olpv.quad_nodes("simpson", 10)), xc=d["xc"].astype(np.float64))
+    for key, ref in (("A", Ao), ("B", Bo), ("C", Co)):
+        scale = np.abs(ref).max()
+        for name in out:
+            err = np.abs(out[name][key].astype(np.float64).reshape(ref.shape) - ref).max() / scale
+            assert err < 2e-6, (name, key, err)
+        assert np.abs(out["panel"][key].astype(np.float64) - out["f32"][key]).max() / scale < 2e-6
+    assert not np.array_equal(out["panel"]["A"], out["f32"]["A"])      # two different kernels did run
 
 
 def test_embedding_kernel_variants_on_the_trained_model(omodel, tmp_path):

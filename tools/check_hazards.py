@@ -4,7 +4,7 @@ The split of an fp32 value into two fp16 planes uses v_fma_mixlo_f16 / v_fma_mix
 the compiler's hazard recognizer does not look into; on gfx950 an MFMA needs two wait states after a VALU write
 of one of its A/B/C operands.  This script disassembles the gfx950 code object embedded in an object file of the
 library and reports every v_mfma that reads a register written by one of those instructions (or by
-v_cvt_pkrtz_f16_f32, which feeds the other plane) fewer than two wait states earlier, for every kernel
+v_cvt_pkrtz_f16_f32 / v_cvt_pk_f16_f32, which feed the other plane) fewer than two wait states earlier, for every kernel
 instantiation in the file.  Exit code 0 = none found.
 
 usage: python tools/check_hazards.py [nmpc_amd/csrc/build/embed.o ...]"""
@@ -16,7 +16,7 @@ import sys
 import tempfile
 
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-WRITERS = ("v_fma_mixlo_f16", "v_fma_mixhi_f16", "v_cvt_pkrtz_f16_f32")
+WRITERS = ("v_fma_mixlo_f16", "v_fma_mixhi_f16", "v_cvt_pkrtz_f16_f32", "v_cvt_pk_f16_f32")
 NEEDED = 2
 
 
@@ -80,7 +80,7 @@ def check(text):
 
 def main(paths):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    paths = paths or [os.path.join(root, "nmpc_amd", "csrc", "build", "embed.o")]
+    paths = paths or [os.path.join(root, "nmpc_amd", "csrc", "build", n) for n in ("embed.o", "embed_panel.o")]
     bad = 0
     for pth in paths:
         kernels, nw, nm, findings = check(disassemble(pth))

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 tag=${1:-r2}
 set -e
 for cfg in cfg3 cfg5; do
-  if [ $cfg = cfg3 ]; then args="--config cfg3 --steps 20 --warmup 5"; kern="mpc_solve_wide_kernel"; else args="--config cfg5 --steps 3 --warmup 1"; kern="embed_wide_kernel"; fi
+  if [ $cfg = cfg3 ]; then args="--config cfg3 --steps 20 --warmup 5"; kern="mpc_solve_wide_kernel"; else args="--config cfg5 --steps 3 --warmup 1"; kern="embed_panel_kernel"; fi
   timeout -k 10 400 python bench.py $args --repeats 2 > gpurun_out/${tag}_${cfg}_bench.json 2> gpurun_out/${tag}_${cfg}_bench.err
   rm -rf gpurun_out/prof_stats_$cfg
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats_$cfg -- python bench.py $args --no-cpu-baseline --latency-steps 0 --repeats 1 > gpurun_out/${tag}_${cfg}_bench_under_rocprof.json 2> gpurun_out/${cfg}_rocprof.err
