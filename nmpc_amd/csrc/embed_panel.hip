@@ -68,17 +68,20 @@ __device__ __forceinline__ f16x8 half_load(__amdgpu_buffer_rsrc_t r, int lane_by
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
 
 template <int HT, int NOUTP, int PT>
-__host__ __device__ constexpr int panel_lds_floats() { return (HT / 2) * PT * NOUTP * 2 * 64 * 4 + NOUTP * 16 * HT; }
+__host__ __device__ constexpr int panel_lds_floats() { return (HT / 2) * 8 * 2 * 64 * 4 + NOUTP * 16 * HT; }
 
 template <int HT, int NOUTP, int PT, int RING, bool LOOP>
 __global__ __launch_bounds__(256, 1) void embed_panel_kernel(PanelArgs a, NodeTable nt) {
     constexpr int H = 16 * HT, KST = HT / 2, KW = KST / 4, CT = PT * NOUTP;
-    constexpr int NST = 2 * KW * KST;       // weight stages of a node: forward then reverse, KW tile pairs of KST k-steps
+    constexpr int NF = KW * KST;            // weight stages of one matrix: KW own tile pairs of KST k-steps
+    constexpr int FCT = HT >= 16 ? 4 : 8;   // column tiles of the forward product (register budget: (1 - t2^2) / 4 of a group stays in registers)
+    constexpr int NGRP = FCT / PT;          // = nodes per group x point tiles
     constexpr int PF = RING - 1;
-    static_assert(KW >= 1 && NST % RING == 0, "ring position must repeat from node to node");
+    constexpr int BR = 4;                   // panel-fragment slots: reads run BR - 1 column tiles ahead
+    static_assert(KW >= 1 && NF % RING == 0 && CT <= 8 && FCT <= 8 && NGRP >= 1, "ring position must repeat from node to node");
     extern __shared__ __align__(16) float plds[];
     f16x8* PANEL = reinterpret_cast<f16x8*>(plds);                  // [k-step][column tile][plane][lane]
-    float* W4S = plds + KST * CT * 2 * 64 * 4;                       // [NOUTP][H]
+    float* W4S = plds + KST * 8 * 2 * 64 * 4;                        // [NOUTP][H]
     f32x4* RED = reinterpret_cast<f32x4*>(plds);                     // [wave][column tile][lane], after the last node
 
     int npts = a.npts;
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(256, 1) void embed_panel_kernel(PanelArgs a, NodeTa
     for (int i = tid; i < NOUTP * H; i += 256) W4S[i] = N.w4s[i];
 
     // per-lane tables of the wave's own units: element j of own k-step i is unit 16 (2 ks + (j >> 2)) + 4 g + (j & 3)
-    float G[KW][PT][8], CB0[KW][8], CB2S[KW][8];
+    float G[KW][PT][8], CB0[KW][8];
     {
         float z[PT][16];
 #pragma unroll
@@ -120,7 +123,6 @@ __global__ __launch_bounds__(256, 1) void embed_panel_kernel(PanelArgs a, NodeTa
             for (int j = 0; j < 8; ++j) {
                 const int unit = 16 * (2 * (wave * KW + i) + (j >> 2)) + 4 * g + (j & 3);
                 CB0[i][j] = N.cb0[unit];
-                CB2S[i][j] = N.cb2s[unit];
                 const f32x4* w0 = reinterpret_cast<const f32x4*>(N.w0g + (size_t)unit * 16);
                 const f32x4 wa = w0[0], wb = w0[1], wc = w0[2], wd = w0[3];
 #pragma unroll
@@ -146,27 +148,21 @@ __global__ __launch_bounds__(256, 1) void embed_panel_kernel(PanelArgs a, NodeTa
             W0l[i] = half_load(W0T, 16 * lane, ((wave * KW + i) * 2 + 1) * 1024);
         }
     }
-    const float inv_sf = N.inv_sf, s_v256 = N.s_v * 0.00390625f;
+    const float inv_sf = N.inv_sf, s_v = N.s_v;
 
-    // Weight stages: stage s of a node = (phase, own tile pair i, k-step kk); its four fragments (two tiles, two
-    // planes) sit in ring slot s % RING and are requested PF stages ahead, across phases and nodes.
+    // Weight stages: a stage = (own tile pair i, k-step kk) of the forward or the reverse matrix; its four
+    // fragments (two tiles, two planes) sit in ring slot s % RING and are requested PF stages ahead.
     const int wbase = wave * KW * 2 * KST * 2048;
     f16x8 Rh[RING][2], Rl[RING][2];
-    auto stage_load = [&](int s, int lo_) {
-        const int ph = s / (KW * KST), i = (s / KST) % KW, kk = s % KST;
+    auto stage_load = [&](bool rev, int s, int lo_) {
+        const int i = s / KST, kk = s % KST;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int off = wbase + (((2 * i + t) * KST + kk) * 2) * 1024;
-            Rh[s % RING][t] = half_load(ph ? REV : FWD, lo_, off);
-            Rl[s % RING][t] = half_load(ph ? REV : FWD, lo_, off + 1024);
+            Rh[s % RING][t] = half_load(rev ? REV : FWD, lo_, off);
+            Rl[s % RING][t] = half_load(rev ? REV : FWD, lo_, off + 1024);
         }
     };
-    {
-        int lo = 16 * lane;
-        asm volatile("" : "+v"(lo));
-#pragma unroll
-        for (int s = 0; s < PF; ++s) stage_load(s, lo);
-    }
 
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 jacc[CT];
@@ -176,150 +172,211 @@ __global__ __launch_bounds__(256, 1) void embed_panel_kernel(PanelArgs a, NodeTa
     float wcur = nn > 0 ? nt.w[0] : 0.0f;
     __syncthreads();                                   // W4S in place
 
-    for (int node = 0; node < nn; ++node) {
-        const float lam = nt.lam[node];
-        const float wn = nt.w[node];
-        if (wn != wcur) {                              // uniform, rare: the sum is kept in units of the current weight
-            const float sc = wcur / wn;
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) jacc[ct] = jacc[ct] * sc;
-            wcur = wn;
-        }
+    // Nodes go in groups of NGRP: the forward product of a whole group is one pass over W2 (its FCT = NGRP PT column
+    // tiles share every weight fragment; alone, a node's forward product would fetch 2 KB per three MFMAs and sit on
+    // the L2 port), then the reverse sweep runs node by node on the (1 - t2^2) / 4 kept in registers.
+#ifdef NMPC_PANEL_STAMPS
+    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tq, tq0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#define STAMP0() tq = __builtin_amdgcn_s_memtime()
+#define STAMP(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tph[k] += t_ - tq; tq = t_; }
+#else
+#define STAMP0()
+#define STAMP(k)
+#endif
+    for (int n0 = 0; n0 < nn; n0 += NGRP) {
+        STAMP0();
         int lo = 16 * lane, ln = lane;
         asm volatile("" : "+v"(lo), "+v"(ln));          // keeps the loop-invariant loads inside the loop
-
-        // layer 1 of the own units; r1 = (1 + t1) / 2 is the operand of the forward product
-        float wd1[KW][PT][8];
-        f16x8 bh[KW][PT], bl[KW][PT];
 #pragma unroll
-        for (int i = 0; i < KW; ++i)
-#pragma unroll
-            for (int pt = 0; pt < PT; ++pt) {
-                float r[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {                        // 256 r1: keeps the fp16 remainder of small r1 normal
-                    const float e = __builtin_amdgcn_exp2f(-fmaf(lam, G[i][pt][j], CB0[i][j]));
-                    const float rp = __builtin_amdgcn_rcpf(fmaf(e, 0.00390625f, 0.00390625f));
-                    r[j] = rp;
-                    const float rr = 0.00390625f * rp, q = s_v256 * rp;
-                    wd1[i][pt][j] = fmaf(-rr, q, q);                 // s_v (1 - t1^2) / 4
-                }
-                split8(r, bh[i][pt], bl[i][pt]);
-            }
+        for (int s = 0; s < PF; ++s) stage_load(false, s, lo);
         __syncthreads();                               // the previous node's reverse panel has been read by every wave
+        // layer 1 of the own units at every node of the group; 256 r1 = 128 (1 + t1) is the forward operand (the
+        // factor keeps the fp16 remainder of small r1 normal)
 #pragma unroll
-        for (int i = 0; i < KW; ++i)
+        for (int ng = 0; ng < NGRP; ++ng) {
+            const float lam = nt.lam[min(n0 + ng, nn - 1)];
 #pragma unroll
-            for (int pt = 0; pt < PT; ++pt) {
-                PANEL[(((wave * KW + i) * PT + pt) * 2 + 0) * 64 + ln] = bh[i][pt];
-                PANEL[(((wave * KW + i) * PT + pt) * 2 + 1) * 64 + ln] = bl[i][pt];
-            }
-        __syncthreads();
-
-        // forward: own tile rows of (s_f 2 c2 W2) r1 + s_f c2 (b2 - W2 1), then (1 - t2^2) / 4 of the own units
-        float d2q[KW][PT][8];
-#pragma unroll
-        for (int i = 0; i < KW; ++i) {
-            f32x4 acc[2][PT];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int pt = 0; pt < PT; ++pt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[t][pt][r] = CB2S[i][4 * t + r];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int kk = 0; kk < KST; ++kk) {
-                const int s = i * KST + kk;
+            for (int i = 0; i < KW; ++i)
 #pragma unroll
                 for (int pt = 0; pt < PT; ++pt) {
-                    const f16x8 BH = PANEL[((kk * PT + pt) * 2 + 0) * 64 + ln];
-                    const f16x8 BL = PANEL[((kk * PT + pt) * 2 + 1) * 64 + ln];
+                    float r[8];
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        acc[t][pt] = MFMA16(Rl[s % RING][t], BH, acc[t][pt]);
-                        acc[t][pt] = MFMA16(Rh[s % RING][t], BL, acc[t][pt]);
-                        acc[t][pt] = MFMA16(Rh[s % RING][t], BH, acc[t][pt]);
+                    for (int j = 0; j < 8; ++j) {
+                        const float e = __builtin_amdgcn_exp2f(-fmaf(lam, G[i][pt][j], CB0[i][j]));
+                        r[j] = __builtin_amdgcn_rcpf(fmaf(e, 0.00390625f, 0.00390625f));
                     }
+                    f16x8 bh, bl;
+                    split8(r, bh, bl);
+                    PANEL[(((wave * KW + i) * FCT + ng * PT + pt) * 2 + 0) * 64 + ln] = bh;
+                    PANEL[(((wave * KW + i) * FCT + ng * PT + pt) * 2 + 1) * 64 + ln] = bl;
                 }
-                stage_load((s + PF) % NST, lo);
+        }
+        __syncthreads();
+        STAMP(0);
+
+        // forward: own tile rows of (s_f 2 c2 W2) (256 r1) + 256 s_f c2 (b2 - W2 1), then (1 - t2^2) / 4 of the own units
+        float d2q[KW][FCT][8];
+#pragma unroll
+        for (int i = 0; i < KW; ++i) {
+            f32x4 acc[2][FCT];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {              // rows 4 g + r of tile 2 ks + t
+                const f32x4 cb = *reinterpret_cast<const f32x4*>(N.cb2s + 16 * (2 * (wave * KW + i) + t) + 4 * g);
+#pragma unroll
+                for (int fc = 0; fc < FCT; ++fc) acc[t][fc] = cb;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // panel fragments are read BR - 1 column tiles ahead of their products (one wave per SIMD: nothing else
+            // would cover the LDS latency)
+            f16x8 pbh[BR], pbl[BR];
+#pragma unroll
+            for (int q = 0; q < BR - 1; ++q) {
+                pbh[q % BR] = PANEL[(q * 2 + 0) * 64 + ln];
+                pbl[q % BR] = PANEL[(q * 2 + 1) * 64 + ln];
+            }
+#pragma unroll
+            for (int q = 0; q < KST * FCT; ++q) {
+                const int kk = q / FCT, fc = q % FCT, s = i * KST + kk;
+                if (q + BR - 1 < KST * FCT) {
+                    pbh[(q + BR - 1) % BR] = PANEL[((q + BR - 1) * 2 + 0) * 64 + ln];
+                    pbl[(q + BR - 1) % BR] = PANEL[((q + BR - 1) * 2 + 1) * 64 + ln];
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    acc[t][fc] = MFMA16(Rl[s % RING][t], pbh[q % BR], acc[t][fc]);
+                    acc[t][fc] = MFMA16(Rh[s % RING][t], pbl[q % BR], acc[t][fc]);
+                    acc[t][fc] = MFMA16(Rh[s % RING][t], pbh[q % BR], acc[t][fc]);
+                }
+                if (fc == FCT - 1) {                   // the last PF requests are the first reverse stages
+                    if (s + PF < NF) stage_load(false, s + PF, lo);
+                    else stage_load(true, s + PF - NF, lo);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int pt = 0; pt < PT; ++pt)
+                for (int fc = 0; fc < FCT; ++fc)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float rr = sigm2p(acc[t][pt][r] * inv_sf);
-                        d2q[i][pt][4 * t + r] = fmaf(-rr, rr, rr);
+                        const float rr = sigm2p(acc[t][fc][r] * inv_sf);
+                        d2q[i][fc][4 * t + r] = fmaf(-rr, rr, rr);
                     }
         }
-        __syncthreads();                               // the forward panel has been read by every wave
 
-        // reverse operands of the own units, one column tile per (point tile, output row)
+        STAMP(1);
+        for (int ng = 0; ng < NGRP; ++ng) {            // not unrolled; d2q[.][0..PT) is the current node's, rotated below
+            const int node = n0 + ng;
+            if (node >= nn) break;
+            const float lam = nt.lam[node];
+            const float wn = nt.w[node];
+            if (wn != wcur) {                          // uniform, rare: the sum is kept in units of the current weight
+                const float sc = wcur / wn;
 #pragma unroll
-        for (int i = 0; i < KW; ++i) {
-            const int ks = wave * KW + i;
+                for (int ct = 0; ct < CT; ++ct) jacc[ct] = jacc[ct] * sc;
+                wcur = wn;
+            }
+            float wd1[KW][PT][8];                      // s_v (1 - t1^2) / 4 of the own units at this node
 #pragma unroll
-            for (int c = 0; c < NOUTP; ++c) {
-                const f32x4 w4a = *reinterpret_cast<const f32x4*>(W4S + c * H + 16 * (2 * ks) + 4 * g);
-                const f32x4 w4b = *reinterpret_cast<const f32x4*>(W4S + c * H + 16 * (2 * ks + 1) + 4 * g);
+            for (int i = 0; i < KW; ++i)
 #pragma unroll
-                for (int pt = 0; pt < PT; ++pt) {
-                    float b[8];
+                for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { b[r] = d2q[i][pt][r] * w4a[r]; b[4 + r] = d2q[i][pt][4 + r] * w4b[r]; }
-                    f16x8 ph, pl;
-                    split8(b, ph, pl);
-                    PANEL[((ks * CT + pt * NOUTP + c) * 2 + 0) * 64 + ln] = ph;
-                    PANEL[((ks * CT + pt * NOUTP + c) * 2 + 1) * 64 + ln] = pl;
+                    for (int j = 0; j < 8; ++j) {
+                        const float rr = sigm2p(fmaf(lam, G[i][pt][j], CB0[i][j]));
+                        const float q = s_v * rr;
+                        wd1[i][pt][j] = fmaf(-rr, q, q);
+                    }
+            __syncthreads();                           // the panel (forward, or the previous node's reverse) has been read by every wave
+            STAMP(2);
+
+            // reverse operands of the own units, one column tile per (point tile, output row); the rows of W4 are
+            // read one step ahead (LDS reads and writes share one in-order counter)
+            {
+                f32x4 w4a[2], w4b[2];
+                w4a[0] = *reinterpret_cast<const f32x4*>(W4S + 16 * (2 * (wave * KW)) + 4 * g);
+                w4b[0] = *reinterpret_cast<const f32x4*>(W4S + 16 * (2 * (wave * KW) + 1) + 4 * g);
+#pragma unroll
+                for (int ic = 0; ic < KW * NOUTP; ++ic) {
+                    const int i = ic / NOUTP, c = ic % NOUTP, ks = wave * KW + i;
+                    if (ic + 1 < KW * NOUTP) {
+                        const int i1 = (ic + 1) / NOUTP, c1 = (ic + 1) % NOUTP, ks1 = wave * KW + i1;
+                        w4a[(ic + 1) & 1] = *reinterpret_cast<const f32x4*>(W4S + c1 * H + 16 * (2 * ks1) + 4 * g);
+                        w4b[(ic + 1) & 1] = *reinterpret_cast<const f32x4*>(W4S + c1 * H + 16 * (2 * ks1 + 1) + 4 * g);
+                    }
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) {
+                        float b[8];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { b[r] = d2q[i][pt][r] * w4a[ic & 1][r]; b[4 + r] = d2q[i][pt][4 + r] * w4b[ic & 1][r]; }
+                        f16x8 ph, pl;
+                        split8(b, ph, pl);
+                        PANEL[((ks * CT + pt * NOUTP + c) * 2 + 0) * 64 + ln] = ph;
+                        PANEL[((ks * CT + pt * NOUTP + c) * 2 + 1) * 64 + ln] = pl;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-        }
-        __syncthreads();
+            __syncthreads();
+            STAMP(3);
 
-        // reverse: own tile rows of (s_r W2^T) (d2 o s_c W4[c]) for every column tile, then the contraction of
-        // s_v d1 o (.) with s_0 W0^T over the own k-step
+            // reverse: own tile rows of (s_r W2^T) (d2 o s_c W4[c]) for every column tile, then the contraction of
+            // s_v d1 o (.) with s_0 W0^T over the own k-step
 #pragma unroll
-        for (int i = 0; i < KW; ++i) {
-            f32x4 racc[2][CT];
+            for (int i = 0; i < KW; ++i) {
+                f32x4 racc[2][CT];
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) racc[t][ct] = zero4;
+                    for (int ct = 0; ct < CT; ++ct) racc[t][ct] = zero4;
+                f16x8 pbh[BR], pbl[BR];
 #pragma unroll
-            for (int kk = 0; kk < KST; ++kk) {
-                const int s = KW * KST + i * KST + kk;
+                for (int q = 0; q < BR - 1; ++q) {
+                    pbh[q % BR] = PANEL[(q * 2 + 0) * 64 + ln];
+                    pbl[q % BR] = PANEL[(q * 2 + 1) * 64 + ln];
+                }
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    const f16x8 BH = PANEL[((kk * CT + ct) * 2 + 0) * 64 + ln];
-                    const f16x8 BL = PANEL[((kk * CT + ct) * 2 + 1) * 64 + ln];
+                for (int q = 0; q < KST * CT; ++q) {
+                    const int kk = q / CT, ct = q % CT, s = i * KST + kk;
+                    if (q + BR - 1 < KST * CT) {
+                        pbh[(q + BR - 1) % BR] = PANEL[((q + BR - 1) * 2 + 0) * 64 + ln];
+                        pbl[(q + BR - 1) % BR] = PANEL[((q + BR - 1) * 2 + 1) * 64 + ln];
+                    }
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
-                        racc[t][ct] = MFMA16(Rl[s % RING][t], BH, racc[t][ct]);
-                        racc[t][ct] = MFMA16(Rh[s % RING][t], BL, racc[t][ct]);
-                        racc[t][ct] = MFMA16(Rh[s % RING][t], BH, racc[t][ct]);
+                        racc[t][ct] = MFMA16(Rl[s % RING][t], pbh[q % BR], racc[t][ct]);
+                        racc[t][ct] = MFMA16(Rh[s % RING][t], pbl[q % BR], racc[t][ct]);
+                        racc[t][ct] = MFMA16(Rh[s % RING][t], pbh[q % BR], racc[t][ct]);
                     }
+                    if (ct == CT - 1) stage_load(true, (s + PF) % NF, lo);    // wraps to the next node's first stages (same matrix)
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                stage_load((s + PF) % NST, lo);        // the last PF requests are the next node's first forward stages
-                __builtin_amdgcn_sched_barrier(0);
-            }
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                const int pt = ct / NOUTP;
-                float u[8];
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int pt = ct / NOUTP;
+                    float u[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) u[j] = racc[j >> 2][ct][j & 3] * wd1[i][pt][j];
-                f16x8 uh, ul;
-                split8(u, uh, ul);
-                jacc[ct] = MFMA16(W0l[i], uh, jacc[ct]);
-                jacc[ct] = MFMA16(W0h[i], ul, jacc[ct]);
-                jacc[ct] = MFMA16(W0h[i], uh, jacc[ct]);
+                    for (int j = 0; j < 8; ++j) u[j] = racc[j >> 2][ct][j & 3] * wd1[i][pt][j];
+                    f16x8 uh, ul;
+                    split8(u, uh, ul);
+                    jacc[ct] = MFMA16(W0l[i], uh, jacc[ct]);
+                    jacc[ct] = MFMA16(W0h[i], ul, jacc[ct]);
+                    jacc[ct] = MFMA16(W0h[i], uh, jacc[ct]);
+                }
             }
+            STAMP(4);
+#pragma unroll
+            for (int i = 0; i < KW; ++i)               // the next node of the group moves to the front
+#pragma unroll
+                for (int fc = 0; fc + PT < FCT; ++fc)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) d2q[i][fc][j] = d2q[i][fc + PT][j];
         }
     }
 
+#ifdef NMPC_PANEL_STAMPS
+    const unsigned long long tq1 = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
+#endif
     // the four waves' partial sums (each over its own hidden units) -> outputs; lane (n, g) holds inputs 4 g + r of point n
     __syncthreads();
 #pragma unroll
@@ -343,6 +400,15 @@ __global__ __launch_bounds__(256, 1) void embed_panel_kernel(PanelArgs a, NodeTa
             else if (j < a.na + a.nb) a.ob[((size_t)row[pt] * a.nout + c) * a.nb + (j - a.na)] = o;
         }
     }
+#ifdef NMPC_PANEL_STAMPS
+    __syncthreads();
+    if (tid == 0 && a.nout * a.na >= 8) {
+        float* o = a.oa + (size_t)row[0] * a.nout * a.na;
+        for (int k = 0; k < 5; ++k) o[k] = (float)tph[k] / (float)nn;
+        o[5] = (float)(tq1 - tq0) / (float)nn;
+        o[6] = (float)(tq1 - tq0) / (float)(rt1 - rt0) * 0.1f;
+    }
+#endif
 }
 
 template <int HT, int NOUTP, int PT, int RING>
@@ -369,8 +435,8 @@ int panel_launch_net(const PanelNet& net, PanelArgs a, const NodeTable& nt, hipS
     a.net = net;
 #define NMPC_PANEL_CASE(HT_, NO_, PT_, RING_) \
     if (net.ht == HT_ && net.nout_pad == NO_) return panel_launch_t<HT_, NO_, PT_, RING_>(a, nt, s, loop);
-    NMPC_PANEL_CASE(8, 1, 4, 4) NMPC_PANEL_CASE(8, 4, 2, 4) NMPC_PANEL_CASE(8, 8, 1, 8)
-    NMPC_PANEL_CASE(16, 1, 4, 4) NMPC_PANEL_CASE(16, 4, 2, 4) NMPC_PANEL_CASE(16, 8, 1, 4)
+    NMPC_PANEL_CASE(8, 1, 4, 4) NMPC_PANEL_CASE(8, 4, 2, 4) NMPC_PANEL_CASE(8, 8, 1, 4)
+    NMPC_PANEL_CASE(16, 1, 4, 4) NMPC_PANEL_CASE(16, 4, 2, 2) NMPC_PANEL_CASE(16, 8, 1, 2)
 #undef NMPC_PANEL_CASE
     set_error("embed: no panel kernel for hidden tiles %d, outputs %d", net.ht, net.nout_pad);
     return 1;
