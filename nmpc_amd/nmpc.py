@@ -215,6 +215,35 @@ class Controller:
         return self.stats()[0]
 
 
+_PROFILE_CHUNK = 256
+
+
+def _timed_loop(ctrl, dev, Nsim):
+    """Runs Nsim closed-loop steps one call at a time with an event after each and the per-launch event pairs of
+    the controller switched on; the pairs are read back (and their events recycled) every _PROFILE_CHUNK steps, so
+    that a long run holds a bounded number of live events.  Returns (per-step seconds [Nsim], per-step kernel ms
+    [Nsim, 3], wall seconds)."""
+    comp_t = np.zeros(Nsim)
+    kms = np.zeros((Nsim, 3))
+    torch.cuda.synchronize(dev)
+    start = time.time()
+    ctrl.profile(1)
+    for k0 in range(0, Nsim, _PROFILE_CHUNK):
+        n = min(_PROFILE_CHUNK, Nsim - k0)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        ev[0].record()
+        for k in range(n):
+            ctrl.run(k0 + k, 1)
+            ev[k + 1].record()
+        kms[k0:k0 + n] = ctrl.profile_read_steps(k0, n)          # synchronises the stream
+        for k in range(n):
+            comp_t[k0 + k] = ev[k].elapsed_time(ev[k + 1]) * 1e-3
+    torch.cuda.synchronize(dev)
+    runtime = time.time() - start
+    ctrl.profile(0)
+    return comp_t, kms, runtime
+
+
 def output_NMPC_linear(system, encoder, u_min, u_max, y_min, y_max, x0, Q, R, dt, dlam, stages, y_reference_list,
                        Nc=5, Nsim=30, max_iterations=1, *, tol=1e-1, rho=1000.0, targets=None, noise=None,
                        return_controller=False):
@@ -261,19 +290,8 @@ def output_NMPC_linear(system, encoder, u_min, u_max, y_min, y_max, x0, Q, R, dt
         noise = torch.randn(Nsim, B, generator=gen, dtype=torch.float64) * float(system.sigma_n[0])
     ctrl.set_targets(Xs.transpose(1, 2).contiguous(), Us[:, 0, :].contiguous(), noise)
     ctrl.reset(x0n, u0n, getattr(system, "x0", None))
-    comp_t_log = np.zeros(Nsim)
-    torch.cuda.synchronize(dev)
-    start = time.time()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(Nsim + 1)]
-    ctrl.profile(1)
-    ev[0].record()
-    for k in range(Nsim):
-        ctrl.run(k, 1)
-        ev[k + 1].record()
-    torch.cuda.synchronize(dev)
-    runtime = time.time() - start
-    for k in range(Nsim):
-        comp_t_log[k] = ev[k].elapsed_time(ev[k + 1]) * 1e-3
+    comp_t_log, kms, runtime = _timed_loop(ctrl, dev, Nsim)
+    kms = kms * 1e-3
     nfail = ctrl.qp_failures()
     if nfail:
         raise _lib.NmpcError("output_NMPC_linear: %d QP solves did not converge" % nfail)
@@ -286,8 +304,6 @@ def output_NMPC_linear(system, encoder, u_min, u_max, y_min, y_max, x0, Q, R, dt
     # k*max_iterations holds step k, so that the reference's analysis (split into Nsim groups of
     # max_iterations columns and sum, CompTime.ipynb cells 3-4) recovers per-step totals.
     components_time = np.zeros((4, Nsim * max_iterations))
-    kms = ctrl.profile_read_steps(0, Nsim) * 1e-3
-    ctrl.profile(0)
     components_time[0, ::max_iterations] = kms[:, 0]
     components_time[1, ::max_iterations] = kms[:, 1]
     components_time[3, ::max_iterations] = kms[:, 2]
@@ -349,21 +365,7 @@ def _state_loop(system, encoder, x_min, x_max, u_min, u_max, x0, Q, R, dt, dlam,
             np.asarray(system.sigma_n, np.float64)[:nx])
     ctrl.set_targets(Xs.transpose(1, 2).contiguous(), Us[:, 0, :].contiguous(), noise)
     ctrl.reset((x0b[0] - y0) / ystd, u0n, x0b[0])
-    comp_t_log = np.zeros(Nsim)
-    torch.cuda.synchronize(dev)
-    start = time.time()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(Nsim + 1)]
-    ctrl.profile(1)
-    ev[0].record()
-    for k in range(Nsim):
-        ctrl.run(k, 1)
-        ev[k + 1].record()
-    torch.cuda.synchronize(dev)
-    runtime = time.time() - start
-    for k in range(Nsim):
-        comp_t_log[k] = ev[k].elapsed_time(ev[k + 1]) * 1e-3
-    kms = ctrl.profile_read_steps(0, Nsim)
-    ctrl.profile(0)
+    comp_t_log, kms, runtime = _timed_loop(ctrl, dev, Nsim)
     nfail = ctrl.qp_failures()
     if nfail:
         raise _lib.NmpcError("state-feedback NMPC: %d QP solves failed (infeasible hard constraints?)" % nfail)

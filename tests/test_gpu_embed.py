@@ -349,6 +349,33 @@ def test_wide_kernel_variants(nx, nu, ny, H, tmp_path):
     assert not np.array_equal(out["panel"]["A"], out["f32"]["A"])      # two different kernels did run
 
 
+def test_panel_kernel_ragged_batches():
+    """The split-fp16 panel kernel works in workgroups of 16, 32 or 64 points (by output count): batches that end inside
+    a workgroup, a single point, an empty batch and node counts that do not fill a node group give, point for point,
+    bitwise the results of the full batch - a point's result does not depend on what shares its workgroup."""
+    import nmpc_amd
+    from oracle.model import Model
+    for nx, nu, ny, H in ((8, 1, 1, 256), (3, 2, 2, 128)):
+        om = Model.synthetic(nx, nu, ny, H, seed=11)
+        params = {k: [np.asarray(a, np.float32) for a in n.params()] for k, n in (("fn", om.fn), ("hn", om.hn))}
+        enc = nmpc_amd.Encoder(params, device="cuda:0")
+        rng = np.random.default_rng(4)
+        P = 131
+        x = torch.tensor(f32(rng.uniform(-2, 2, (P, nx)))); u = torch.tensor(f32(rng.uniform(-2, 2, (P, nu))))
+        xc = torch.tensor(f32(rng.uniform(-2, 2, (P, nx))))
+        for stages in (10, 3, 1):                       # 20, 6 and 2 nodes: whole groups, a partial group, less than a group
+            lam, w = nmpc_amd.quad_nodes("simpson", stages)
+            A, B, C = nmpc_amd.embed(enc, x, u, xc, lam, w)
+            for n in (0, 1, 15, 16, 17, 63, 64, 65, 130):
+                An, Bn, Cn = nmpc_amd.embed(enc, x[:n], u[:n], xc[:n], lam, w)
+                assert An.shape == (n, nx, nx) and Bn.shape == (n, nx, nu) and Cn.shape == (n, ny, nx)
+                assert torch.equal(An, A[:n]) and torch.equal(Bn, B[:n]) and torch.equal(Cn, C[:n])
+            Ao, Bo, Co = olpv.embed(om, x.numpy().astype(np.float64), u.numpy().astype(np.float64),
+                                    *olpv.merge_nodes(*olpv.quad_nodes("simpson", stages)), xc=xc.numpy().astype(np.float64))
+            for got, ref in ((A, Ao), (B, Bo), (C, Co)):
+                assert np.abs(got.cpu().numpy().astype(np.float64).reshape(ref.shape) - ref).max() / np.abs(ref).max() < 2e-6
+
+
 def test_embedding_kernel_variants_on_the_trained_model(omodel, tmp_path):
     """The three kernels that can serve the disc model - split-fp16 MFMA (default, with and without the stepped
     layer-1 exponentials), fp32 MFMA (NMPC_EMBED=f32), general-width (NMPC_EMBED=wide) - on the trained weights and
