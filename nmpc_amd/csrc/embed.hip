@@ -261,13 +261,21 @@ __device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, fl
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, hq = lane >> 4;
-    {
+    {   // stage the packed net: all loads of a lane in flight before the first LDS write (a load-then-store loop
+        // would pay the L2 latency once per 16 bytes)
+        constexpr int NV = (4096 + 4096 * NOUT) / 4 / EMBED_THREADS;
+        static_assert((4096 + 4096 * NOUT) / 4 % EMBED_THREADS == 0 && PK_TAIL / 4 <= EMBED_THREADS, "fill plan");
         const f32x4* src = reinterpret_cast<const f32x4*>(pack);
         f32x4* dst = reinterpret_cast<f32x4*>(lds);
-        for (int i = tid; i < (4096 + 4096 * NOUT) / 4; i += EMBED_THREADS) dst[i] = src[i];
         const f32x4* src2 = reinterpret_cast<const f32x4*>(pack + PK_REC1);
         f32x4* dst2 = reinterpret_cast<f32x4*>(lds + L_REC1);
-        for (int i = tid; i < PK_TAIL / 4; i += EMBED_THREADS) dst2[i] = src2[i];
+        f32x4 stage[NV], stage2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < NV; ++k) stage[k] = src[tid + k * EMBED_THREADS];
+        if (tid < PK_TAIL / 4) stage2 = src2[tid];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) dst[tid + k * EMBED_THREADS] = stage[k];
+        if (tid < PK_TAIL / 4) dst2[tid] = stage2;
     }
     __syncthreads();
     // fragment planes: [plane][T][ks][lane] of 8 halves (16 B)
