@@ -9,6 +9,7 @@
 
 #include "mpc_kernels.h"
 #include "mpc_wide.h"
+#include "mpc_tail.h"
 
 namespace nmpc {
 
@@ -433,6 +434,7 @@ struct nmpc_ctrl {
     ModelDev m;
     NodeTable nt;
     MpcGeom g;
+    int tail_from = 0;                // LPV passes from this one on run in the per-controller tail kernel (0: none do)
     std::vector<void*> allocs;
     int device;
     int prof_every = 0;               // 0: off; n: event pairs around the launches of steps k % n == 0
@@ -534,6 +536,14 @@ extern "C" int nmpc_ctrl_create(nmpc_ctrl** out, const nmpc_model* m, const nmpc
         if (p && hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeDevice) d.stamps = (unsigned long long*)p;
     }
     if (rc) { nmpc_ctrl_destroy(c); return 1; }
+    // Passes from tail_from on go to one per-controller launch (mpc_tail.hip) where the work list is expected to be
+    // almost empty: after two batch-wide passes when at most four passes are allowed (the reference's setting, with
+    // its stop tolerance of 0.1); runs that iterate to convergence (more passes allowed) keep batch-wide passes.
+    // NMPC_CTRL_TAIL=p overrides (0: never).
+    c->tail_from = (d.maxit >= 3 && d.maxit <= 4) ? 2 : 0;
+    if (const char* e = getenv("NMPC_CTRL_TAIL")) c->tail_from = atoi(e);
+    if (c->tail_from < 1 || c->tail_from >= d.maxit || !mpc_tail_applies(d, c->m, c->g) ||
+        mpc_wide_applies(d.Nc, d.nx, d.c.mode, d.c.slack)) c->tail_from = 0;
     // slices: NMPC_CTRL_SLICES (1..8) overrides the default (3 from 1536 controllers, 2 from 1024, else 1;
     // three slice streams and the caller's stream fill the four hardware queues of a process)
     int ns = B >= 1536 ? 3 : (B >= 1024 ? 2 : 1);
@@ -643,7 +653,8 @@ extern "C" int nmpc_ctrl_run(nmpc_ctrl* c, int k0, int nsteps, const double* Xs,
             hipStream_t s = multi ? sl.stream : s0;
             const CtrlDev& d = sl.d;
             const RunPtrs& rp = sl_rp[i];
-            for (int it = 0; it < d.maxit; ++it) {
+            const int wide_passes = c->tail_from > 0 ? c->tail_from : d.maxit;
+            for (int it = 0; it < wide_passes; ++it) {
                 EmbedArgs a{};
                 a.x = d.xs32; a.u = d.us32; a.A = d.A32; a.B = d.B32;
                 if (d.c.mode == 0) { a.xc = d.xc32; a.C = d.C32; }
@@ -655,6 +666,12 @@ extern "C" int nmpc_ctrl_run(nmpc_ctrl* c, int k0, int nsteps, const double* Xs,
                 prof_end(c, on, s, pr);
                 on = prof_begin(c, 1, k, s, pr);
                 if (dispatch_mpc_solve(d, rp, it, k, c->g, s)) return 1;
+                prof_end(c, on, s, pr);
+            }
+            if (c->tail_from > 0) {
+                ProfRec pr;
+                const bool on = prof_begin(c, 1, k, s, pr);          // counted with the solves (mostly an empty launch)
+                if (launch_mpc_tail(d, rp, c->m, c->nt, c->tail_from, k, s)) return 1;
                 prof_end(c, on, s, pr);
             }
             ProfRec pr;

@@ -45,6 +45,8 @@ int embed_launch(const ModelDev& m, EmbedArgs a, const NodeTable& nt, hipStream_
 // on the model and the caller's nodes: callers that launch repeatedly prepare it once.
 int embed_prepare_nodes(const ModelDev& m, const NodeTable& nodes, NodeTable& prepared);
 int embed_launch_prepared(const ModelDev& m, EmbedArgs a, const NodeTable& prepared, hipStream_t stream, bool loop = false);
+// true unless NMPC_EMBED selects another kernel than the split-fp16 one for the 64-wide nets
+bool embed_split16_selected();
 // general-width kernel (embed_wide.hip); nt must already have its lambda = 0 nodes folded into w_zero
 int embed_wide_launch(const ModelDev& m, const EmbedArgs& a, const NodeTable& nt, hipStream_t stream, bool loop);
 

@@ -359,18 +359,15 @@ struct RunPtrs {
     int noise_ld;   // controllers per row of `noise` (the whole batch, also for a slice view)
 };
 
+// One LPV pass of controller b by one group of GS lanes (lane gl of the group): condensing, QP assembly and solve,
+// prediction, stop test; writes the plan, the prediction and the next pass's scheduling points.  Returns (to every
+// lane of the group) whether the controller needs another pass.
 template <int GS, int MPL, int NX, int NC = 0>
-__global__ __launch_bounds__(NX > 4 ? 256 : 1024) void mpc_solve_kernel(CtrlDev d, RunPtrs rp, int it, int k) {
-    extern __shared__ __align__(16) double mpc_lds[];
-    const int gpb = blockDim.x / GS, g = threadIdx.x / GS, gl = threadIdx.x % GS;
-    const int gid = blockIdx.x * gpb + g;
-    const int count = it == 0 ? d.B : min(d.nact[it], d.B);
-    if (gid >= count) return;
-    const int b = it == 0 ? gid : d.act[(size_t)it * d.B + gid];
+__device__ __forceinline__ bool mpc_solve_body(const CtrlDev& d, const RunPtrs& rp, int it, int k, int b, double* lds, int gl) {
     const int Nc = NC ? NC : d.Nc, n = NC ? NC + 1 : mpc_nvar(Nc, d.c.slack), mt = NC ? 4 * NC + 2 : mpc_nrows(Nc, NX, d.c.mode);
     const int ntot = d.n_sim + Nc;
     MpcLds L;
-    L.carve(mpc_lds + (size_t)g * mpc_lds_doubles(Nc, NX, n, mt), Nc, NX, n, mt);
+    L.carve(lds, Nc, NX, n, mt);
     for (int e = gl; e < Nc * NX * NX; e += GS) L.Ak[e] = (double)d.A32[(size_t)b * Nc * NX * NX + e];
     for (int e = gl; e < Nc * NX; e += GS) {
         L.Bk[e] = (double)d.B32[(size_t)b * Nc * NX + e];
@@ -413,10 +410,23 @@ __global__ __launch_bounds__(NX > 4 ? 256 : 1024) void mpc_solve_kernel(CtrlDev 
         if (st != 0) atomicAdd(d.qp_fail, 1ull);
         d.qp_stat[2 * b] += 1u;                 // per-controller tallies: no shared-address atomics
         d.qp_stat[2 * b + 1] += (unsigned)qp_it;
-        if (it + 1 < d.maxit && !(sqrt(du) < d.tol)) {
-            const int pos = atomicAdd(&d.nact[it + 1], 1);
-            d.act[(size_t)(it + 1) * d.B + pos] = b;
-        }
+    }
+    return it + 1 < d.maxit && !(sqrt(du) < d.tol);
+}
+
+template <int GS, int MPL, int NX, int NC = 0>
+__global__ __launch_bounds__(NX > 4 ? 256 : 1024) void mpc_solve_kernel(CtrlDev d, RunPtrs rp, int it, int k) {
+    extern __shared__ __align__(16) double mpc_lds[];
+    const int gpb = blockDim.x / GS, g = threadIdx.x / GS, gl = threadIdx.x % GS;
+    const int gid = blockIdx.x * gpb + g;
+    const int count = it == 0 ? d.B : min(d.nact[it], d.B);
+    if (gid >= count) return;
+    const int b = it == 0 ? gid : d.act[(size_t)it * d.B + gid];
+    const int Nc = NC ? NC : d.Nc, n = NC ? NC + 1 : mpc_nvar(Nc, d.c.slack), mt = NC ? 4 * NC + 2 : mpc_nrows(Nc, NX, d.c.mode);
+    const bool more = mpc_solve_body<GS, MPL, NX, NC>(d, rp, it, k, b, mpc_lds + (size_t)g * mpc_lds_doubles(Nc, NX, n, mt), gl);
+    if (gl == 0 && more) {
+        const int pos = atomicAdd(&d.nact[it + 1], 1);
+        d.act[(size_t)(it + 1) * d.B + pos] = b;
     }
 }
 

@@ -200,6 +200,28 @@ def test_slices_do_not_change_results(enc, monkeypatch):
             assert torch.equal(outs[0][i], o[i]), i
 
 
+def test_tail_kernel_does_not_change_results(enc, monkeypatch):
+    """LPV passes 3 and 4 of the canonical configuration run in one per-controller launch (embedding tile + solve body
+    in a loop) instead of two batch-wide launches each; switching that off, or starting the per-controller launch one
+    pass earlier or later, must not change a single bit of the logs.  Noisy measurements and a tight stop tolerance
+    make a sizeable share of the controllers take three and four passes."""
+    import nmpc_amd
+    B, Nsim, Nc = 301, 25, 10
+    refs = np.stack([random_level_reference(Nsim + Nc, [10, 15], [-1, 1], np.random.default_rng(150 + b)) for b in range(B)])
+    noise = 0.014 * np.random.default_rng(12).standard_normal((Nsim, B))
+    plant = nmpc_amd.OutputUnbalancedDisc(dt=0.1, sigma_n=[0.014])
+    outs = []
+    for tail in ("0", "2", "1", "3"):
+        monkeypatch.setenv("NMPC_CTRL_TAIL", tail)
+        outs.append(nmpc_amd.output_NMPC_linear(plant, enc, -4, 4, [-1.2], [1.2], np.zeros(2), Q, 1.0, 0.1, 0.05, 20, refs,
+                                                Nc=Nc, Nsim=Nsim, max_iterations=4, tol=1e-3, noise=noise))
+    cnt = outs[0][6].cpu().numpy()
+    assert (cnt >= 3).mean() > 0.05 and (cnt == 4).any()          # the later passes are exercised
+    for o in outs[1:]:
+        for i in (0, 1, 2, 6, 8, 9):
+            assert torch.equal(outs[0][i], o[i]), i
+
+
 def test_closed_loop_long_horizon(enc, omodel):
     """Nc = 50 (the long-horizon configuration: 51 QP variables, 202 rows), bounds u in [-3, 3],
     y in [-1, 1] (NMPC_output.py:226-227), 3 controllers x 15 steps against the oracle."""
