@@ -15,6 +15,8 @@
 
 namespace nmpc {
 
+constexpr int TAIL_GRID = 64;     // workgroups of a tail launch (each walks the work list with this stride)
+
 struct TailArgs {
     const float* fpack;
     const float* hpack;
@@ -26,11 +28,13 @@ __global__ __launch_bounds__(EMBED_THREADS, 1) void mpc_tail_kernel(CtrlDev d, R
     extern __shared__ __align__(16) float tail_lds[];
     __shared__ int more_s;
     const int count = min(d.nact[t.it0], d.B);
-    if ((int)blockIdx.x >= count) return;
-    const int* slot = d.act + (size_t)t.it0 * d.B + blockIdx.x;
-    const int b = *slot;
     constexpr int tiles = (NC + EMBED_TILE - 1) / EMBED_TILE;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // a small grid walks the work list: the launch is empty most of the time, and a workgroup of this kernel needs a
+    // whole CU's registers, so every workgroup that is only dispatched to exit would still wait for one
+    for (int w = blockIdx.x; w < count; w += gridDim.x) {
+    const int* slot = d.act + (size_t)t.it0 * d.B + w;
+    const int b = *slot;
     for (int it = t.it0; it < d.maxit; ++it) {
         // the scheduling points of this pass were written by the solve of the previous one (another kernel for
         // it0, wave 0 of this workgroup afterwards): complete the stores, drop this CU's cached lines
@@ -57,6 +61,8 @@ __global__ __launch_bounds__(EMBED_THREADS, 1) void mpc_tail_kernel(CtrlDev d, R
         __syncthreads();
         if (!more_s) break;
     }
+    __syncthreads();                                  // more_s and the LDS are reused by the next controller
+    }
 }
 
 static size_t tail_lds_bytes(const CtrlDev& d, const ModelDev& m) {
@@ -81,7 +87,8 @@ static int tail_launch_t(const CtrlDev& d, const RunPtrs& rp, const TailArgs& t,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));   // beside 16 B static
         mark_used_on_device(once);
     }
-    hipLaunchKernelGGL((mpc_tail_kernel<2, 1, 1, 1, 10, RECUR>), dim3(d.B), dim3(EMBED_THREADS), lds, s, d, rp, t, nt, k);
+    const int grid = d.B < TAIL_GRID ? d.B : TAIL_GRID;
+    hipLaunchKernelGGL((mpc_tail_kernel<2, 1, 1, 1, 10, RECUR>), dim3(grid), dim3(EMBED_THREADS), lds, s, d, rp, t, nt, k);
     NMPC_HIP_CHECK(hipGetLastError());
     return 0;
 }
