@@ -67,8 +67,13 @@ __device__ __forceinline__ f16x8 half_load(__amdgpu_buffer_rsrc_t r, int lane_by
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
 
+// layer-1 slopes of the own units in LDS: only where the register budget needs it and the panel leaves room
+template <int HT, int PT>
+__host__ __device__ constexpr bool GLDS() { return HT == 16 && PT == 1; }
 template <int HT, int NOUTP, int PT>
-__host__ __device__ constexpr int panel_lds_floats() { return (HT / 2) * 8 * 2 * 64 * 4 + NOUTP * 16 * HT; }
+__host__ __device__ constexpr int panel_lds_floats() {
+    return (HT / 2) * 8 * 2 * 64 * 4 + NOUTP * 16 * HT + (GLDS<HT, PT>() ? (HT / 8) * PT * 8 * 256 + 16 * HT : 0);
+}
 
 template <int HT, int NOUTP, int PT, int RING, bool LOOP>
 __global__ __launch_bounds__(256, 1) void embed_panel_kernel(PanelArgs a, NodeTable nt) {
@@ -103,9 +108,13 @@ __global__ __launch_bounds__(256, 1) void embed_panel_kernel(PanelArgs a, NodeTa
         row[pt] = a.act ? a.act[pc / a.group] * a.group + pc % a.group : pc;
     }
     for (int i = tid; i < NOUTP * H; i += 256) W4S[i] = N.w4s[i];
+    if constexpr (GLDS<HT, PT>()) for (int i = tid; i < H; i += 256) (W4S + NOUTP * H + (HT / 8) * PT * 8 * 256)[i] = N.cb0[i];
 
     // per-lane tables of the wave's own units: element j of own k-step i is unit 16 (2 ks + (j >> 2)) + 4 g + (j & 3)
-    float G[KW][PT][8], CB0[KW][8];
+    constexpr bool GL = GLDS<HT, PT>();     // layer-1 slopes in LDS instead of registers (frees 8 KW PT registers)
+    float* GLp = W4S + NOUTP * H;           // [KW][PT][8][256] floats when GL
+    float* CB0S = GLp + KW * PT * 8 * 256;  // [H] c2 b0 when GL
+    float G[GL ? 1 : KW][GL ? 1 : PT][8], CB0[GL ? 1 : KW][8];
     {
         float z[PT][16];
 #pragma unroll
@@ -122,7 +131,7 @@ __global__ __launch_bounds__(256, 1) void embed_panel_kernel(PanelArgs a, NodeTa
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int unit = 16 * (2 * (wave * KW + i) + (j >> 2)) + 4 * g + (j & 3);
-                CB0[i][j] = N.cb0[unit];
+                if constexpr (!GL) CB0[i][j] = N.cb0[unit];
                 const f32x4* w0 = reinterpret_cast<const f32x4*>(N.w0g + (size_t)unit * 16);
                 const f32x4 wa = w0[0], wb = w0[1], wc = w0[2], wd = w0[3];
 #pragma unroll
@@ -133,7 +142,7 @@ __global__ __launch_bounds__(256, 1) void embed_panel_kernel(PanelArgs a, NodeTa
                         s = fmaf(wa[q], z[pt][q], s); s = fmaf(wb[q], z[pt][4 + q], s);
                         s = fmaf(wc[q], z[pt][8 + q], s); s = fmaf(wd[q], z[pt][12 + q], s);
                     }
-                    G[i][pt][j] = s;
+                    if constexpr (GL) GLp[((i * PT + pt) * 8 + j) * 256 + tid] = s; else G[i][pt][j] = s;
                 }
             }
     }
@@ -202,7 +211,10 @@ __global__ __launch_bounds__(256, 1) void embed_panel_kernel(PanelArgs a, NodeTa
                     float r[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float e = __builtin_amdgcn_exp2f(-fmaf(lam, G[i][pt][j], CB0[i][j]));
+                        float gv, cb;
+                        if constexpr (GL) { gv = GLp[((i * PT + pt) * 8 + j) * 256 + tid]; cb = CB0S[16 * (2 * (wave * KW + i) + (j >> 2)) + 4 * g + (j & 3)]; }
+                        else { gv = G[i][pt][j]; cb = CB0[i][j]; }
+                        const float e = __builtin_amdgcn_exp2f(-fmaf(lam, gv, cb));
                         r[j] = __builtin_amdgcn_rcpf(fmaf(e, 0.00390625f, 0.00390625f));
                     }
                     f16x8 bh, bl;
@@ -283,7 +295,10 @@ __global__ __launch_bounds__(256, 1) void embed_panel_kernel(PanelArgs a, NodeTa
                 for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float rr = sigm2p(fmaf(lam, G[i][pt][j], CB0[i][j]));
+                        float gv, cb;
+                        if constexpr (GL) { gv = GLp[((i * PT + pt) * 8 + j) * 256 + tid]; cb = CB0S[16 * (2 * (wave * KW + i) + (j >> 2)) + 4 * g + (j & 3)]; }
+                        else { gv = G[i][pt][j]; cb = CB0[i][j]; }
+                        const float rr = sigm2p(fmaf(lam, gv, cb));
                         const float q = s_v * rr;
                         wd1[i][pt][j] = fmaf(-rr, q, q);
                     }
@@ -436,7 +451,7 @@ int panel_launch_net(const PanelNet& net, PanelArgs a, const NodeTable& nt, hipS
 #define NMPC_PANEL_CASE(HT_, NO_, PT_, RING_) \
     if (net.ht == HT_ && net.nout_pad == NO_) return panel_launch_t<HT_, NO_, PT_, RING_>(a, nt, s, loop);
     NMPC_PANEL_CASE(8, 1, 4, 4) NMPC_PANEL_CASE(8, 4, 2, 4) NMPC_PANEL_CASE(8, 8, 1, 4)
-    NMPC_PANEL_CASE(16, 1, 4, 4) NMPC_PANEL_CASE(16, 4, 2, 2) NMPC_PANEL_CASE(16, 8, 1, 2)
+    NMPC_PANEL_CASE(16, 1, 4, 4) NMPC_PANEL_CASE(16, 4, 2, 2) NMPC_PANEL_CASE(16, 8, 1, 4)
 #undef NMPC_PANEL_CASE
     set_error("embed: no panel kernel for hidden tiles %d, outputs %d", net.ht, net.nout_pad);
     return 1;
