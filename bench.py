@@ -338,7 +338,9 @@ def closed_loop_bench(args, cfgname, rank, world, dev, shard):
         n_launch, ms_embed, sampled = 0, float("nan"), []
     # algorithmic flops of the event-bracketed launches: passes of this rank in the sampled steps
     fpp = NODES_EVALUATED * FLOPS_PER_POINT_NODE
-    embed_flops = fpp * NC * float(lpv[:, sampled].sum().item()) if sampled else float("nan")
+    # (passes from tail_from on run in the per-controller tail launch, which is timed with the solves)
+    wide = lpv if not ctrl.tail_from else torch.clamp(lpv, max=ctrl.tail_from)
+    embed_flops = fpp * NC * float(wide[:, sampled].sum().item()) if sampled else float("nan")
     iso = isolated_embed_tflops(nmpc_amd, enc, lam, w, B * NC, dev)
     y = gathered["y_log"][:B, W + 1:W + K + 1]
     track = float((y - torch.clamp(torch.as_tensor(refs[:, W:W + K], device=dev), ylo, yhi)).abs().median().item())
@@ -348,7 +350,7 @@ def closed_loop_bench(args, cfgname, rank, world, dev, shard):
     roof_embed = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                   "traffic": None,
                   "traffic_note": "not measured in this run; PMC passes of the same command are under profiles/ "
-                                  "(r2_pmc_*.txt: ~1.1 MB of HBM traffic per launch, weights and points)",
+                                  "(r2c_pmc_embed_loop.txt: FETCH_SIZE + WRITE_SIZE ~1.0 MB of HBM traffic per launch, weights and points)",
                   "peak_note": "dense f16 MFMA peak (16 x 157.3) / 3 products per f32 product; achieved = algorithmic f32 "
                                "flops of the %d nodes the kernel evaluates (the lambda = 0 node of the 41 is a host "
                                "constant) / event-timed launch span; launches of different slices overlap each other" % NODES_EVALUATED,
@@ -364,8 +366,10 @@ def closed_loop_bench(args, cfgname, rank, world, dev, shard):
                   "traffic": None, "kernel": "mpc_solve_wide_kernel" if NC >= 24 else "mpc_solve_kernel", "launches": n_solve,
                   "avg_launch_ms": ms_solve / max(n_solve, 1), "bytes_per_controller_pass": sb,
                   "note": "condense + QP + prediction, one %s per controller, everything between A/B/C and the "
-                          "plan stays in LDS/registers: latency-bound, HBM traffic is the algorithmic minimum"
-                          % ("workgroup of four wavefronts" if NC >= 24 else "wavefront")}
+                          "plan stays in LDS/registers: latency-bound, HBM traffic is the algorithmic minimum%s"
+                          % ("workgroup of four wavefronts" if NC >= 24 else "wavefront",
+                             "; launches include the per-controller tail launch (passes >= %d: embedding + solve in one kernel)"
+                             % (ctrl.tail_from + 1) if ctrl.tail_from else "")}
     dominant_solve = n_solve and ms_solve > ms_embed
     res = {
         "metric": "closed-loop NMPC controller-steps/sec (B=4096, N=10)" if cfgname == "cfg2" else

@@ -173,6 +173,10 @@ int nmpc_ctrl_profile_read(nmpc_ctrl* c, int* launches, double* total_ms, void* 
 /* Same record, per step: ms[nsteps][3] = summed launch durations of steps k0 .. k0+nsteps-1 per kind
  * (the getAB / solve / sim buckets of the reference's components_time, NMPC_test.py:152-300). */
 int nmpc_ctrl_profile_read_steps(nmpc_ctrl* c, int k0, int nsteps, double* ms, void* stream);
+/* The LPV re-scheduling loop of a step (NMPC_test.py:154-260) runs its first passes as batch-wide launches and,
+ * for the canonical shapes, the remaining ones in one per-controller launch: returns the first pass (0-based) that
+ * runs there, 0 if none does.  Launches of that kernel are timed with kind 1. */
+int nmpc_ctrl_tail_from(const nmpc_ctrl* c);
 
 /* ---- steady-state target selector (reference: mpcUtil.py:241-320 getXsUs_Cs, called pre-loop at
  * NMPC_test.py:79-80).  For every reference sample j, warm-started from sample j-1, iterate LPV passes:

@@ -61,6 +61,7 @@ SIGNATURES = {
     "nmpc_ctrl_profile": (ctypes.c_int, [c_void_p, ctypes.c_int]),
     "nmpc_ctrl_profile_read": (ctypes.c_int, [c_void_p, c_int_p, c_double_p, c_void_p]),
     "nmpc_ctrl_profile_read_steps": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, c_double_p, c_void_p]),
+    "nmpc_ctrl_tail_from": (ctypes.c_int, [c_void_p]),
     "nmpc_ctrl_stats": (ctypes.c_int, [c_void_p, ctypes.POINTER(ctypes.c_longlong), c_void_p]),
 }
 

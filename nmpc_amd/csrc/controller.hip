@@ -711,6 +711,8 @@ extern "C" int nmpc_ctrl_profile(nmpc_ctrl* c, int enable) {
     return 0;
 }
 
+extern "C" int nmpc_ctrl_tail_from(const nmpc_ctrl* c) { return c ? c->tail_from : 0; }
+
 extern "C" int nmpc_ctrl_profile_read(nmpc_ctrl* c, int* launches, double* total_ms, void* stream) {
     NMPC_REQUIRE(c && launches && total_ms, "nmpc_ctrl_profile_read: null argument");
     NMPC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));

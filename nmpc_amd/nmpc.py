@@ -195,6 +195,11 @@ class Controller:
             check(lib().nmpc_ctrl_profile_read(self.handle, n, ms, current_stream()), "nmpc_ctrl_profile_read")
         return {k: (int(n[i]), float(ms[i])) for i, k in enumerate(("embed", "solve", "plant"))}
 
+    @property
+    def tail_from(self):
+        """First LPV pass (0-based) that runs in the per-controller tail launch; 0 if every pass is a batch-wide launch."""
+        return int(lib().nmpc_ctrl_tail_from(self.handle))
+
     def profile_read_steps(self, k0, nsteps):
         """[nsteps, 3] ms per step and kind (embed, solve, plant) since the last read."""
         ms = np.zeros((nsteps, 3))
