@@ -15,8 +15,11 @@
 //     buffer_load from L2, prefetched through a register ring) feeds 3 CT MFMAs per tile;
 //   * forward (W2 r1), reverse (W2^T (d2 o W4[c])) and the contraction with W0 chain through registers: an
 //     accumulator pair of tiles (2 ks, 2 ks + 1) is by construction the B operand of k-step ks (PanelNet).
-// Four barriers per node order the two uses of the panel.  Scales (powers of two chosen by the host so that every
-// operand sits near unit scale, where the unscaled fp16 remainder resolves 2^-24) are undone in the last step.
+//   * the forward product is taken for a group of nodes at once (FCT column tiles = nodes x point tiles share each
+//     fragment of W2), the reverse sweep then runs node by node from the (1 - t2^2) / 4 kept in registers.
+// Two barriers per node and three per group order the uses of the panel.  Scales (powers of two chosen by the host
+// so that every operand sits towards the top of the fp16 range, where the fp16 remainder is a normal number) are
+// undone in the last step.
 #include "../../include/nmpc_amd.h"
 #include "common.h"
 #include "embed.h"
