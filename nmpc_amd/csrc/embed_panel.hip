@@ -204,6 +204,7 @@ __global__ __launch_bounds__(256, 1) void embed_panel_kernel(PanelArgs a, NodeTa
         __syncthreads();                               // the previous node's reverse panel has been read by every wave
         // layer 1 of the own units at every node of the group; 256 r1 = 128 (1 + t1) is the forward operand (the
         // factor keeps the fp16 remainder of small r1 normal)
+        float wd1[KW][PT][8];                          // s_v (1 - t1^2) / 4 of the own units at the node being swept
 #pragma unroll
         for (int ng = 0; ng < NGRP; ++ng) {
             const float lam = nt.lam[min(n0 + ng, nn - 1)];
@@ -219,6 +220,10 @@ __global__ __launch_bounds__(256, 1) void embed_panel_kernel(PanelArgs a, NodeTa
                         else { gv = G[i][pt][j]; cb = CB0[i][j]; }
                         const float e = __builtin_amdgcn_exp2f(-fmaf(lam, gv, cb));
                         r[j] = __builtin_amdgcn_rcpf(fmaf(e, 0.00390625f, 0.00390625f));
+                        if constexpr (NGRP == 1) {     // a group of one node: its layer-1 slopes are these
+                            const float rr = 0.00390625f * r[j], q = s_v * rr;
+                            wd1[i][pt][j] = fmaf(-rr, q, q);
+                        }
                     }
                     f16x8 bh, bl;
                     split8(r, bh, bl);
@@ -291,7 +296,7 @@ __global__ __launch_bounds__(256, 1) void embed_panel_kernel(PanelArgs a, NodeTa
                 for (int ct = 0; ct < CT; ++ct) jacc[ct] = jacc[ct] * sc;
                 wcur = wn;
             }
-            float wd1[KW][PT][8];                      // s_v (1 - t1^2) / 4 of the own units at this node
+            if constexpr (NGRP > 1)
 #pragma unroll
             for (int i = 0; i < KW; ++i)
 #pragma unroll
