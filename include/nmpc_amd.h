@@ -33,6 +33,10 @@ typedef struct nmpc_ctrl nmpc_ctrl;
 /* quadrature rules of the reference's lpv_int.py / par_lpv_int.py */
 enum { NMPC_RULE_SIMPSON = 0, NMPC_RULE_TRAP = 1 };
 
+/* Version of this header; nmpc_version() returns the library's.  Bumped whenever a struct layout or a signature
+ * changes (110: nmpc_ctrl_config gained struct_size / as_written and eight-entry state bounds, status log added). */
+#define NMPC_AMD_VERSION 110
+
 const char* nmpc_last_error(void);
 int nmpc_version(void);
 
@@ -101,7 +105,10 @@ int nmpc_qp_solve(int nb, int n, int m, int meq, const double* P, const double* 
  * Inputs (device fp64): list_A[nb,Nc*nx,nx] list_B[nb,Nc*nx,1] list_C[nb,Nc,nx] x0[nb,nx] y_meas[nb]
  * Xs[nb,Nc*nx] Us[nb,Nc]; host: f0[nx] h0 Q[nx*nx] R rho and NORMALISED bounds.
  * Outputs (device fp64, each may be NULL): Ge[nb,n,n] (lower triangle valid) Fe[nb,n] Le[nb,m,n]
- * hv[nb,m] with n = Nc+1, m = 4Nc+2;  u[nb,Nc] eps[nb] xpred[nb,Nc*nx] status[nb] (int). */
+ * hv[nb,m] with n = Nc+1, m = 4Nc+2;  u[nb,Nc] eps[nb] xpred[nb,Nc*nx] status[nb] (int).
+ * Diagnostics: with the environment variable NMPC_MPC_STAMPS set to the address (hex) of a device buffer of
+ * 16 * nb 64-bit words (16 * batch for nmpc_ctrl_create, which reads it too), the kernels store 16 shader-clock
+ * stamps per problem there; the buffer must stay valid while the handle / call is in use. */
 int nmpc_mpc_qp(int nb, int Nc, int nx, const double* list_A, const double* list_B, const double* list_C,
                 const double* x0, const double* y_meas, const double* Xs, const double* Us, const double* f0,
                 double h0, const double* Q, double R, double rho, double u_min, double u_max, double y_min,
@@ -114,6 +121,7 @@ int nmpc_mpc_qp(int nb, int Nc, int nx, const double* list_A, const double* list
  * prediction update} until ||u - u_old||_2 < tol, then plant RK4 step, measurement, observer,
  * logging and warm-start shift.  Controllers that have converged drop out of the later passes. */
 typedef struct nmpc_ctrl_config {
+    int struct_size;                     /* sizeof(nmpc_ctrl_config) of the caller's header; checked by nmpc_ctrl_create */
     int batch, Nc, max_iterations, n_sim;
     double tol;                          /* NMPC_test.py:257 */
     double rho;                          /* slack weight, NMPC_test.py:225 */
@@ -136,8 +144,12 @@ typedef struct nmpc_ctrl_config {
      * width up to 256: the reference's larger encoders, LTI.ipynb cell 5, sinCos.ipynb cell 6, and the synthetic wide
      * configuration); x_log holds the model state, y_log / y_est_log the noisy / noise-free output. */
     int mode, hard;
-    double x_min[4], x_max[4];
-    double x_norm0[4], x_normstd[4];
+    double x_min[8], x_max[8];
+    double x_norm0[8], x_normstd[8];
+    /* mode 1 only.  0 (default): input targets follow the step, Us = us[k .. k+Nc), and the linear cost term is
+     * 2 (Gamma' Omega (Phi x0 - Xs) - Psi Us), what output_NMPC_linear does for the same step (NMPC_test.py:152,213).
+     * 1: par_NMPC_linear as written - Us = us[0 .. Nc) at every step (NMPC.py:580) and + Psi' Us (NMPC.py:591). */
+    int as_written;
     /* observer histories (NMPC_test.py:115-118: uhist has encoder.na entries, yhist encoder.nb + 1; the encoder
      * net reads [uhist, yhist]).  Their sum must equal the model's n_enc_in; 0, 0 = (n_enc_in - 1) / 2 inputs
      * and the rest outputs. */
@@ -157,6 +169,13 @@ int nmpc_ctrl_reset(nmpc_ctrl* c, const double* x0n, double u0n, const double* p
 int nmpc_ctrl_run(nmpc_ctrl* c, int k0, int nsteps, const double* Xs, const double* Us, const double* noise,
                   double* x_log, double* u_log, double* e_log, double* y_log, double* y_est_log,
                   int* lpv_counter, double* plan_log, void* stream);
+/* Per-controller QP status (reference: qp.solve_qp returning None would raise at NMPC_test.py:233-235 and end the
+ * run).  Here a controller whose QP solve fails (status as nmpc_qp_solve: 1 iteration limit, 2 infeasible, 3 Hessian
+ * not positive definite) keeps the plan it came with - the previous step's plan, shifted - for that step, takes no
+ * further LPV pass in it, and the worst status of the step's solves is written to qp_status_log[batch, n_sim]
+ * (device, int8; 0 = all solves of the step succeeded) by later nmpc_ctrl_run calls; the other controllers of the
+ * batch are not affected.  NULL (the default) switches the log off. */
+int nmpc_ctrl_set_status_log(nmpc_ctrl* c, signed char* qp_status_log);
 /* stats[3] (host): [0] (controller, pass) QP solves since reset that did not return status 0,
  * [1] QP solves, [2] active-set iterations summed over them.  Synchronises the stream. */
 int nmpc_ctrl_stats(nmpc_ctrl* c, long long* stats, void* stream);

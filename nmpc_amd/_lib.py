@@ -63,6 +63,7 @@ SIGNATURES = {
     "nmpc_ctrl_profile_read_steps": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, c_double_p, c_void_p]),
     "nmpc_ctrl_tail_from": (ctypes.c_int, [c_void_p]),
     "nmpc_ctrl_stats": (ctypes.c_int, [c_void_p, ctypes.POINTER(ctypes.c_longlong), c_void_p]),
+    "nmpc_ctrl_set_status_log": (ctypes.c_int, [c_void_p, c_void_p]),
 }
 
 MAX_NODES = 256
@@ -70,7 +71,7 @@ MAX_NODES = 256
 
 class CtrlConfig(ctypes.Structure):
     """struct nmpc_ctrl_config of include/nmpc_amd.h"""
-    _fields_ = [("batch", ctypes.c_int), ("Nc", ctypes.c_int), ("max_iterations", ctypes.c_int),
+    _fields_ = [("struct_size", ctypes.c_int), ("batch", ctypes.c_int), ("Nc", ctypes.c_int), ("max_iterations", ctypes.c_int),
                 ("n_sim", ctypes.c_int), ("tol", ctypes.c_double), ("rho", ctypes.c_double),
                 ("Q", ctypes.c_double * 64), ("R", ctypes.c_double),
                 ("u_min", ctypes.c_double), ("u_max", ctypes.c_double), ("y_min", ctypes.c_double),
@@ -79,9 +80,14 @@ class CtrlConfig(ctypes.Structure):
                 ("plant", ctypes.c_double * 6), ("n_nodes", ctypes.c_int),
                 ("lam", ctypes.c_float * MAX_NODES), ("w", ctypes.c_float * MAX_NODES),
                 ("mode", ctypes.c_int), ("hard", ctypes.c_int),
-                ("x_min", ctypes.c_double * 4), ("x_max", ctypes.c_double * 4),
-                ("x_norm0", ctypes.c_double * 4), ("x_normstd", ctypes.c_double * 4),
+                ("x_min", ctypes.c_double * 8), ("x_max", ctypes.c_double * 8),
+                ("x_norm0", ctypes.c_double * 8), ("x_normstd", ctypes.c_double * 8),
+                ("as_written", ctypes.c_int),
                 ("n_uhist", ctypes.c_int), ("n_yhist", ctypes.c_int)]
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.struct_size = ctypes.sizeof(CtrlConfig)
 
 
 _lib = None

@@ -115,6 +115,8 @@ __global__ __launch_bounds__(64 * PLANT_WAVES) void plant_kernel(CtrlDev d, RunP
         if (rp.u_log) rp.u_log[(size_t)b * ns + k] = u_den;
         if (rp.e_log) rp.e_log[(size_t)b * ns + k] = d.eps[b];
         if (rp.lpv_counter) rp.lpv_counter[(size_t)b * ns + k] = d.cnt[b];
+        if (rp.qp_status_log) rp.qp_status_log[(size_t)b * ns + k] = (signed char)d.qp_worst[b];
+        d.qp_worst[b] = 0;
     }
     if (lane < NX) {
         if (rp.x_log) rp.x_log[((size_t)b * (ns + 1) + k + 1) * NX + lane] = zest[lane];
@@ -225,6 +227,8 @@ __global__ __launch_bounds__(256) void plant_model_kernel(CtrlDev d, RunPtrs rp,
         if (rp.u_log) rp.u_log[(size_t)b * ns + k] = d.ustd * u_n + d.u0;
         if (rp.e_log) rp.e_log[(size_t)b * ns + k] = epsv;
         if (rp.lpv_counter) rp.lpv_counter[(size_t)b * ns + k] = cntv;
+        if (rp.qp_status_log) rp.qp_status_log[(size_t)b * ns + k] = (signed char)d.qp_worst[b];
+        d.qp_worst[b] = 0;
     }
     if (tid < NX) {
         double v = 0.0;
@@ -282,6 +286,8 @@ __global__ void plant_state_kernel(CtrlDev d, RunPtrs rp, int k) {
     if (rp.u_log) rp.u_log[(size_t)b * ns + k] = u_den;
     if (rp.e_log) rp.e_log[(size_t)b * ns + k] = d.eps[b];
     if (rp.lpv_counter) rp.lpv_counter[(size_t)b * ns + k] = d.cnt[b];
+    if (rp.qp_status_log) rp.qp_status_log[(size_t)b * ns + k] = (signed char)d.qp_worst[b];
+    d.qp_worst[b] = 0;
     for (int i = 0; i < Nc; ++i) {
         const double uv = up[i];
         if (rp.plan_log) rp.plan_log[((size_t)b * ns + k) * Nc + i] = uv;
@@ -317,7 +323,7 @@ __global__ void reset_kernel(CtrlDev d, double u0n, State8 x0s, double pw, doubl
     }
     for (int i = 0; i < Nc; ++i) { d.uplan[(size_t)b * Nc + i] = u0n; d.us32[(size_t)b * Nc + i] = (float)u0n; }
     d.ymeas[b] = 0.0; d.eps[b] = 0.0; d.cnt[b] = 0;
-    d.qp_stat[2 * b] = 0u; d.qp_stat[2 * b + 1] = 0u;
+    d.qp_stat[2 * b] = 0u; d.qp_stat[2 * b + 1] = 0u; d.qp_worst[b] = 0;
     if (d.wcnt) d.wcnt[b] = 0;
     d.xp[2 * b] = pw; d.xp[2 * b + 1] = pth;
     for (int j = 0; j < d.na; ++j) d.uhist[(size_t)b * d.na + j] = 0.0;
@@ -434,6 +440,7 @@ struct nmpc_ctrl {
     ModelDev m;
     NodeTable nt;
     MpcGeom g;
+    signed char* qp_status_log = nullptr;   // caller's per-step status log (nmpc_ctrl_set_status_log), may be null
     int tail_from = 0;                // LPV passes from this one on run in the per-controller tail kernel (0: none do)
     std::vector<void*> allocs;
     int device;
@@ -458,6 +465,9 @@ static void prof_end(nmpc_ctrl* c, bool on, hipStream_t s, ProfRec& r) {
 
 extern "C" int nmpc_ctrl_create(nmpc_ctrl** out, const nmpc_model* m, const nmpc_ctrl_config* cfg) {
     NMPC_REQUIRE(out && m && cfg, "nmpc_ctrl_create: null argument");
+    NMPC_REQUIRE(cfg->struct_size == (int)sizeof(nmpc_ctrl_config),
+                 "nmpc_ctrl_create: cfg->struct_size is %d, this library's nmpc_ctrl_config has %d bytes (caller built against "
+                 "another version of nmpc_amd.h?)", cfg->struct_size, (int)sizeof(nmpc_ctrl_config));
     NMPC_REQUIRE(on_device(m->device), "nmpc_ctrl_create: the model lives on device %d, which is not the current device", m->device);
     NMPC_REQUIRE(m->d.nu == 1 && m->d.ny == 1, "nmpc_ctrl_create: closed loop needs nu = ny = 1 (as the reference)");
     const int mode = cfg->mode;
@@ -495,7 +505,9 @@ extern "C" int nmpc_ctrl_create(nmpc_ctrl** out, const nmpc_model* m, const nmpc
     fill_const(d.c, Nc, nx, cfg->Q, cfg->R, cfg->rho, cfg->u_min, cfg->u_max, cfg->y_min, cfg->y_max, m->d.f0, m->d.h0[0]);
     if (mode == 1) {   // the state-feedback controllers drop the model offset (rhs_c, NMPC.py:387,520)
         d.c.mode = 1; d.c.slack = slack;
-        for (int r = 0; r < 4; ++r) { d.c.f0[r] = 0.0; d.c.xmin[r] = cfg->x_min[r]; d.c.xmax[r] = cfg->x_max[r]; d.x0v[r] = cfg->x_norm0[r]; d.xstdv[r] = r < nx ? cfg->x_normstd[r] : 1.0; }
+        d.c.as_written = cfg->as_written ? 1 : 0; d.us_fixed = d.c.as_written;
+        static_assert(sizeof(cfg->x_min) == sizeof(d.c.xmin) && sizeof(cfg->x_norm0) == sizeof(d.x0v), "state bounds / normalisation: config and device constants differ in size");
+        for (int r = 0; r < 8; ++r) { d.c.f0[r] = 0.0; d.c.xmin[r] = cfg->x_min[r]; d.c.xmax[r] = cfg->x_max[r]; d.x0v[r] = cfg->x_norm0[r]; d.xstdv[r] = r < nx ? cfg->x_normstd[r] : 1.0; }
     }
     d.u0 = cfg->u0; d.ustd = cfg->ustd; d.y0 = cfg->y0; d.ystd = cfg->ystd; d.dt = cfg->dt;
     for (int i = 0; i < 6; ++i) d.plant[i] = cfg->plant[i];
@@ -520,6 +532,7 @@ extern "C" int nmpc_ctrl_create(nmpc_ctrl** out, const nmpc_model* m, const nmpc
     rc |= alloc((void**)&d.yhist, sb * (d.nyh > 0 ? d.nyh : 1) * 8); rc |= alloc((void**)&d.eps, sb * 8);
     rc |= alloc((void**)&d.cnt, sb * 4); rc |= alloc((void**)&d.act, sb * (d.maxit + 1) * 4);
     rc |= alloc((void**)&d.nact, (size_t)(d.maxit + 2) * MAX_SLICES * 4); rc |= alloc((void**)&d.qp_fail, 8); rc |= alloc((void**)&d.qp_stat, sb * 8);
+    rc |= alloc((void**)&d.qp_worst, sb * 4);
     rc |= alloc((void**)&d.xs32, sb * Nc * nx * 4); rc |= alloc((void**)&d.us32, sb * Nc * 4);
     rc |= alloc((void**)&d.xc32, sb * Nc * nx * 4); rc |= alloc((void**)&d.A32, sb * Nc * nx * nx * 4);
     rc |= alloc((void**)&d.B32, sb * Nc * nx * 4); rc |= alloc((void**)&d.C32, sb * Nc * nx * 4);
@@ -560,7 +573,7 @@ extern "C" int nmpc_ctrl_create(nmpc_ctrl** out, const nmpc_model* m, const nmpc
         sl.b0 = b0; sl.d.B = b1 - b0;
         sl.d.x0n += o * nx; sl.d.xpred += o * Nc * nx; sl.d.uplan += o * Nc; sl.d.ymeas += o; sl.d.xp += o * 2;
         sl.d.uhist += o * d.na; sl.d.yhist += o * d.nyh; sl.d.eps += o; sl.d.cnt += o;
-        sl.d.act += o * (d.maxit + 1); sl.d.nact += (size_t)(d.maxit + 2) * i; sl.d.qp_stat += o * 2;
+        sl.d.act += o * (d.maxit + 1); sl.d.nact += (size_t)(d.maxit + 2) * i; sl.d.qp_stat += o * 2; sl.d.qp_worst += o;
         sl.d.xs32 += o * Nc * nx; sl.d.us32 += o * Nc; sl.d.xc32 += o * Nc * nx;
         sl.d.A32 += o * Nc * nx * nx; sl.d.B32 += o * Nc * nx; sl.d.C32 += o * Nc * nx;
         if (d.wset) { sl.d.wset += o * 64; sl.d.wcnt += o; }
@@ -640,6 +653,7 @@ extern "C" int nmpc_ctrl_run(nmpc_ctrl* c, int k0, int nsteps, const double* Xs,
         rp.y_est_log = y_est_log ? y_est_log + o * (ns + 1) : nullptr;
         rp.plan_log = plan_log ? plan_log + o * ns * Nc : nullptr;
         rp.lpv_counter = lpv_counter ? lpv_counter + o * ns : nullptr;
+        rp.qp_status_log = c->qp_status_log ? c->qp_status_log + o * ns : nullptr;
         sl_rp.push_back(rp);
         (void)d; (void)s;
     }
@@ -703,6 +717,12 @@ extern "C" int nmpc_ctrl_run(nmpc_ctrl* c, int k0, int nsteps, const double* Xs,
             NMPC_HIP_CHECK(hipStreamWaitEvent(s0, sl.done, 0));
         }
     return rc;
+}
+
+extern "C" int nmpc_ctrl_set_status_log(nmpc_ctrl* c, signed char* qp_status_log) {
+    NMPC_REQUIRE(c, "nmpc_ctrl_set_status_log: null argument");
+    c->qp_status_log = qp_status_log;
+    return 0;
 }
 
 extern "C" int nmpc_ctrl_profile(nmpc_ctrl* c, int enable) {

@@ -307,11 +307,36 @@ static void eval_net_at_zero(const float* const* p, int L, int n_out, int hidden
 using namespace nmpc;
 
 extern "C" const char* nmpc_last_error(void) { return g_err.c_str(); }
-extern "C" int nmpc_version(void) { return 100; }
+extern "C" int nmpc_version(void) { return NMPC_AMD_VERSION; }
 
 // Packs and uploads the nets into `m` (zero-initialised); on failure the caller destroys `m`.
 static int model_fill(nmpc_model* m, int nx, int nu, int ny, int hidden, int Lf, int Lh, int n_enc_in,
                       const float* const* fn, const float* const* hn, const float* const* enc) {
+    // Two-hidden-layer nets narrower than 64 units (the reference trains 32-wide encoders too: UnbalancedDisc.ipynb,
+    // n_nodes_per_layer = 32; CasADiExp takes any width, mpcUtil.py:6-31) are padded to 64 with units whose weights
+    // and biases are zero: tanh(0) = 0 feeds nothing forward and the zero rows / columns of W2 and W4 pass nothing
+    // back, so values and Jacobians are those of the net as given, and the 64-wide kernels and the observer loop
+    // serve it.
+    if (hidden < HID && Lf == 2 && Lh == 2) {
+        std::vector<std::vector<float>> store;
+        store.reserve(24);
+        auto pad = [&](const float* const* p, int n_in, int n_out, const float* q[8]) {
+            auto keep = [&](std::vector<float> v) { store.push_back(std::move(v)); return store.back().data(); };
+            std::vector<float> w0((size_t)HID * n_in, 0.f), b0(HID, 0.f), w2((size_t)HID * HID, 0.f), b2(HID, 0.f), w4((size_t)n_out * HID, 0.f);
+            for (int k = 0; k < hidden; ++k) {
+                for (int j = 0; j < n_in; ++j) w0[(size_t)k * n_in + j] = p[2][(size_t)k * n_in + j];
+                b0[k] = p[3][k]; b2[k] = p[5][k];
+                for (int i = 0; i < hidden; ++i) w2[(size_t)k * HID + i] = p[4][(size_t)k * hidden + i];
+                for (int c = 0; c < n_out; ++c) w4[(size_t)c * HID + k] = p[6][(size_t)c * hidden + k];
+            }
+            q[0] = p[0]; q[1] = p[1]; q[2] = keep(std::move(w0)); q[3] = keep(std::move(b0)); q[4] = keep(std::move(w2));
+            q[5] = keep(std::move(b2)); q[6] = keep(std::move(w4)); q[7] = p[7];
+        };
+        const float *fq[8], *hq[8], *eq[8];
+        pad(fn, nx + nu, nx, fq); pad(hn, nx, ny, hq);
+        if (enc) pad(enc, n_enc_in, nx, eq);
+        return model_fill(m, nx, nu, ny, HID, Lf, Lh, n_enc_in, fq, hq, enc ? eq : nullptr);
+    }
     // the 64-wide kernels (embed.hip) are instantiated for these sizes; everything else runs on the
     // general-width kernel (embed_wide.hip)
     const bool narrow = hidden == HID && nu == 1 && ny == 1 && (nx == 2 || nx == 3) && Lf == 2 && Lh == 2;

@@ -25,6 +25,7 @@ namespace nmpc {
 // mpcUtil.py:112-134).  slack = 1: one extra variable with weight rho and coefficient -1 on every row.
 struct MpcConst {
     int Nc, mode, slack;
+    int as_written;                     // mode 1 only: the linear term adds Psi Us (NMPC.py:591) instead of subtracting it
     double Q[64];                       // nx * nx, row-major (nx <= 8)
     double R, rho, umin, umax, ymin, ymax, h0;
     double f0[8];
@@ -196,7 +197,7 @@ __device__ __forceinline__ void mpc_assemble(const MpcConst& c, MpcLds& L, doubl
         }
         if (on) {
             Lm[a_ * n + b_] = 2.0 * (g + (a_ == b_ ? c.R : 0.0));
-            if (a_ == b_) L.qp.xt[a_] = 2.0 * (f - c.R * L.Us[a_]);
+            if (a_ == b_) L.qp.xt[a_] = 2.0 * (f + ((NC == 0 && c.as_written) ? c.R : -c.R) * L.Us[a_]);
             if (!state_rows) {
                 // y_{a+1} = C_a x_{a+1} + h0:  rows -/+ of block a+1 (the last block has its own two rows)
                 double cg = 0.0;
@@ -331,13 +332,15 @@ struct CtrlDev {
     double tol;
     MpcConst c;
     double u0, ustd, y0, ystd, dt;
-    double x0v[4], xstdv[4];   // state normalisation of the state-feedback mode (norm.y0, norm.ystd vectors)
+    double x0v[8], xstdv[8];   // state normalisation of the state-feedback mode (norm.y0, norm.ystd vectors)
     double plant[6];
     // state (fp64)
     double *x0n, *xpred, *uplan, *ymeas, *xp, *uhist, *yhist, *eps;
     int *cnt, *act, *nact;
     unsigned long long* qp_fail;   // failed solves
     unsigned* qp_stat;             // [B][2]: solves, active-set iterations per controller
+    int* qp_worst;                 // [B]: worst QP status among the passes of the current step (cleared by the plant kernels)
+    int us_fixed;                  // state feedback as written: the input targets of every step are Us[0 .. Nc) (NMPC.py:580)
     // fp32 scheduling points and embedding outputs
     float *xs32, *us32, *xc32, *A32, *B32, *C32;
     const float *enc, *hplain, *fplain;
@@ -356,6 +359,7 @@ struct RunPtrs {
     const double *Xs, *Us, *noise;
     double *x_log, *u_log, *e_log, *y_log, *y_est_log, *plan_log;
     int* lpv_counter;
+    signed char* qp_status_log;   // [batch, n_sim]: worst QP status of the step's passes (0 = every solve succeeded)
     int noise_ld;   // controllers per row of `noise` (the whole batch, also for a slice view)
 };
 
@@ -376,7 +380,7 @@ __device__ __forceinline__ bool mpc_solve_body(const CtrlDev& d, const RunPtrs& 
         L.Xs[e] = rp.Xs[((size_t)b * ntot + (k + 1 + i)) * NX + r];
     }
     for (int e = gl; e < Nc; e += GS) {
-        L.Us[e] = rp.Us[(size_t)b * ntot + k + e];
+        L.Us[e] = rp.Us[(size_t)b * ntot + ((NC == 0 && d.us_fixed) ? 0 : k) + e];
         L.uold[e] = d.uplan[(size_t)b * Nc + e];
     }
     for (int e = gl; e < NX; e += GS) L.x0[e] = d.x0n[(size_t)b * NX + e];
@@ -387,6 +391,19 @@ __device__ __forceinline__ bool mpc_solve_body(const CtrlDev& d, const RunPtrs& 
     if constexpr (GS == 64 && NC > 0 && NC + 1 <= 16) st = gi_solve<GS, MPL, NC + 1>(n, mt, 0, L.qp, nullptr, &qp_it);
     else st = (GS == 64 && n <= 16) ? gi_solve<GS, MPL, (GS == 64 ? 16 : 0)>(n, mt, 0, L.qp, nullptr, &qp_it)
                                     : gi_solve<GS, MPL>(n, mt, 0, L.qp, nullptr, &qp_it);
+    if (st != 0) {
+        // A failed solve (infeasible hard constraints, iteration limit, indefinite Hessian) leaves no plan: the
+        // controller keeps the plan, prediction and scheduling points it came with (the previous step's, shifted),
+        // takes no further pass in this step and is flagged in the status log; the rest of the batch is unaffected.
+        if (gl == 0) {
+            d.cnt[b] = it + 1;
+            atomicAdd(d.qp_fail, 1ull);
+            d.qp_stat[2 * b] += 1u;
+            d.qp_stat[2 * b + 1] += (unsigned)qp_it;
+            if (st > d.qp_worst[b]) d.qp_worst[b] = st;
+        }
+        return false;
+    }
     const double epsv = n > Nc ? L.qp.xt[Nc] : 0.0;
     mpc_predict<GS, NX, NC>(d.c, L, gl);
     double du = 0.0;
@@ -407,7 +424,6 @@ __device__ __forceinline__ bool mpc_solve_body(const CtrlDev& d, const RunPtrs& 
     if (gl == 0) {
         d.eps[b] = epsv;
         d.cnt[b] = it + 1;
-        if (st != 0) atomicAdd(d.qp_fail, 1ull);
         d.qp_stat[2 * b] += 1u;                 // per-controller tallies: no shared-address atomics
         d.qp_stat[2 * b + 1] += (unsigned)qp_it;
     }

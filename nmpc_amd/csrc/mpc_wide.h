@@ -920,6 +920,16 @@ __global__ __launch_bounds__(WIDE_THREADS) void mpc_solve_wide_kernel(CtrlDev d,
     __syncthreads();
     int qp_it = 0;
     const int st = wide_solve<NX, KH>(d.c, L, d.ymeas[b], &qp_it, nullptr, stp, &warm);
+    if (st != 0) {          // workgroup-uniform: keep the plan the controller came with, flag it (see mpc_solve_body)
+        if (tid == 0) {
+            d.cnt[b] = it + 1;
+            atomicAdd(d.qp_fail, 1ull);
+            d.qp_stat[2 * b] += 1u;
+            d.qp_stat[2 * b + 1] += (unsigned)qp_it;
+            if (st > d.qp_worst[b]) d.qp_worst[b] = st;
+        }
+        return;
+    }
     double du = 0.0;
     for (int e = tid; e < Nc; e += WIDE_THREADS) {
         const double un = L.usol[e], dd = un - L.uold[e];
@@ -938,7 +948,6 @@ __global__ __launch_bounds__(WIDE_THREADS) void mpc_solve_wide_kernel(CtrlDev d,
         if (tid == 0) {
             d.eps[b] = L.usol[Nc];
             d.cnt[b] = it + 1;
-            if (st != 0) atomicAdd(d.qp_fail, 1ull);
             d.qp_stat[2 * b] += 1u;
             d.qp_stat[2 * b + 1] += (unsigned)qp_it;
             if (it + 1 < d.maxit && !(sqrt(du) < d.tol)) {

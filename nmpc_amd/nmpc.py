@@ -98,7 +98,8 @@ class Controller:
     def __init__(self, encoder, system, batch, Nc, Nsim, max_iterations, Q, R, u_min_n, u_max_n, y_min_n, y_max_n,
                  nodes, weights, tol=1e-1, rho=1000.0, state_feedback=None):
         """state_feedback: None for the output-feedback controller, or a dict(x_min, x_max [nx] normalised
-        state bounds, y0, ystd [nx] state normalisation, hard=bool) for the state-feedback controllers."""
+        state bounds, y0, ystd [nx] state normalisation, hard=bool, as_written=bool) for the state-feedback
+        controllers (as_written: input targets and linear cost term as NMPC.py:580,591 have them)."""
         model_plant = isinstance(system, ModelPlant)
         if encoder.nx not in ((2, 3, 4, 5, 6, 7, 8) if model_plant else (2, 3, 4)):
             raise _lib.NmpcError("closed-loop controllers support nx = 2..4, with the model as plant 2..8 (model has nx = %d)"
@@ -129,6 +130,7 @@ class Controller:
             cfg.n_uhist, cfg.n_yhist = int(encoder.na), int(encoder.nb) + 1
         if state_feedback is not None:
             cfg.mode, cfg.hard = 1, int(bool(state_feedback.get("hard", False)))
+            cfg.as_written = int(bool(state_feedback.get("as_written", False)))
             for i in range(encoder.nx):
                 cfg.x_min[i] = float(np.asarray(state_feedback["x_min"]).reshape(-1)[i])
                 cfg.x_max[i] = float(np.asarray(state_feedback["x_max"]).reshape(-1)[i])
@@ -146,7 +148,9 @@ class Controller:
         z = lambda *s, dt=torch.float64: torch.zeros(s, dtype=dt, device=dev)
         B, Ns = self.B, self.Nsim
         self.logs = dict(x_log=z(B, Ns + 1, self.nx), u_log=z(B, Ns), e_log=z(B, Ns), y_log=z(B, Ns + 1),
-                         y_est_log=z(B, Ns + 1), lpv_counter=z(B, Ns, dt=torch.int32), plan_log=z(B, Ns, Nc))
+                         y_est_log=z(B, Ns + 1), lpv_counter=z(B, Ns, dt=torch.int32), plan_log=z(B, Ns, Nc),
+                         qp_status=z(B, Ns, dt=torch.int8))
+        check(lib().nmpc_ctrl_set_status_log(self.handle, ptr(self.logs["qp_status"])), "nmpc_ctrl_set_status_log")
 
     def __del__(self):
         h = getattr(self, "handle", None)
@@ -219,6 +223,26 @@ class Controller:
     def qp_failures(self):
         return self.stats()[0]
 
+    def failed_mask(self):
+        """[B, Nsim] bool: controller b had a QP solve fail in step k (it then held its previous plan, shifted)."""
+        return self.logs["qp_status"] != 0
+
+
+def _report_failures(ctrl, what, on_qp_failure):
+    """Per-controller handling of failed QP solves (the reference would stop at NMPC_test.py:233-235 with the
+    first one): the loop has already kept every other controller going; say so, or raise if asked to."""
+    nfail = ctrl.qp_failures()
+    if not nfail or on_qp_failure == "ignore":
+        return
+    mask = ctrl.failed_mask()
+    msg = ("%s: %d QP solves failed in %d of %d controllers (first: controller %d); those controllers held their "
+           "previous plan in the steps concerned, see the status log"
+           % (what, nfail, int(mask.any(1).sum()), mask.shape[0], int(mask.any(1).nonzero()[0, 0]) if mask.any() else -1))
+    if on_qp_failure == "raise":
+        raise _lib.NmpcError(msg)
+    import warnings
+    warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
 
 _PROFILE_CHUNK = 256
 
@@ -251,7 +275,7 @@ def _timed_loop(ctrl, dev, Nsim):
 
 def output_NMPC_linear(system, encoder, u_min, u_max, y_min, y_max, x0, Q, R, dt, dlam, stages, y_reference_list,
                        Nc=5, Nsim=30, max_iterations=1, *, tol=1e-1, rho=1000.0, targets=None, noise=None,
-                       return_controller=False):
+                       return_controller=False, return_status=False, on_qp_failure="warn"):
     """Output-constrained LPV-NMPC with observer (NMPC_test.py:22-320), batched.
 
     y_reference_list: [B, >= Nsim+Nc] (or 1-D for one controller) output reference in physical units.
@@ -259,7 +283,9 @@ def output_NMPC_linear(system, encoder, u_min, u_max, y_min, y_max, x0, Q, R, dt
     getXsUs_Cs when omitted.  noise: optional [Nsim, B] measurement noise; drawn from
     N(0, system.sigma_n[0]) with system.seed when omitted and sigma_n > 0.
     Returns the reference's 12-tuple (x_log, u_log, e_log, comp_t_log, t, runtime, lpv_counter,
-    components_time, y_log, y_est_log, Xs, Us)."""
+    components_time, y_log, y_est_log, Xs, Us); with return_status=True a 13th entry, the int8 status log
+    [B, Nsim] (0 = every QP solve of that controller's step succeeded).  on_qp_failure: "warn" (default), "raise"
+    or "ignore" - a controller whose solve fails holds its previous plan for that step, the others run on."""
     _lib.require_gpu()
     dev = encoder.device
     nx, nu, ny = encoder.nx, encoder.nu, encoder.ny
@@ -297,9 +323,7 @@ def output_NMPC_linear(system, encoder, u_min, u_max, y_min, y_max, x0, Q, R, dt
     ctrl.reset(x0n, u0n, getattr(system, "x0", None))
     comp_t_log, kms, runtime = _timed_loop(ctrl, dev, Nsim)
     kms = kms * 1e-3
-    nfail = ctrl.qp_failures()
-    if nfail:
-        raise _lib.NmpcError("output_NMPC_linear: %d QP solves did not converge" % nfail)
+    _report_failures(ctrl, "output_NMPC_linear", on_qp_failure)
     L = ctrl.logs
     x_log = L["x_log"].clone(); x_log[:, 0, :] = torch.as_tensor(x0, device=dev)   # NMPC_test.py:88
     x_log = x_log.reshape(B, (Nsim + 1) * nx)
@@ -315,6 +339,8 @@ def output_NMPC_linear(system, encoder, u_min, u_max, y_min, y_max, x0, Q, R, dt
     components_time[2, ::max_iterations] = np.maximum(comp_t_log - kms.sum(1), 0.0)
     out = [x_log, L["u_log"], e_log, comp_t_log, t, runtime, L["lpv_counter"], components_time, L["y_log"],
            L["y_est_log"], Xs, Us]
+    if return_status:
+        out.append(L["qp_status"])
     if single:
         out = [o[0] if torch.is_tensor(o) else o for o in out]
     if return_controller:
@@ -323,7 +349,7 @@ def output_NMPC_linear(system, encoder, u_min, u_max, y_min, y_max, x0, Q, R, dt
 
 
 def _state_loop(system, encoder, x_min, x_max, u_min, u_max, x0, Q, R, dt, dlam, stages, x_reference_list, Nc, Nsim,
-                max_iterations, tol, rho, hard, noise, C, targets):
+                max_iterations, tol, rho, hard, noise, C, targets, as_written=False, on_qp_failure="warn", what="state-feedback NMPC"):
     """Shared body of par_NMPC_linear / NMPC_linear: returns (x_log, u_log, e_log, comp_t_log, t, runtime,
     lpv_counter, reference_list_normalized, per-step kernel ms [Nsim, 3], controller)."""
     from .target import getXsUs, GetABC
@@ -363,7 +389,8 @@ def _state_loop(system, encoder, x_min, x_max, u_min, u_max, x0, Q, R, dt, dlam,
     if not np.all(x0b == x0b[0]):
         raise _lib.NmpcError("state-feedback loops start every controller of a batch from the same x0")
     ctrl = Controller(encoder, system, B, Nc, Nsim, max_iterations, Q, R, umin_n, umax_n, 0.0, 0.0, lam, w, tol=tol,
-                      rho=rho, state_feedback=dict(x_min=xmin_n, x_max=xmax_n, y0=y0, ystd=ystd, hard=hard))
+                      rho=rho, state_feedback=dict(x_min=xmin_n, x_max=xmax_n, y0=y0, ystd=ystd, hard=hard,
+                                                   as_written=as_written))
     if noise is None and any(float(sg) > 0 for sg in system.sigma_n):
         gen = torch.Generator(device="cpu"); gen.manual_seed(system.seed)
         noise = torch.randn(Nsim, B, nx, generator=gen, dtype=torch.float64) * torch.as_tensor(
@@ -371,9 +398,7 @@ def _state_loop(system, encoder, x_min, x_max, u_min, u_max, x0, Q, R, dt, dlam,
     ctrl.set_targets(Xs.transpose(1, 2).contiguous(), Us[:, 0, :].contiguous(), noise)
     ctrl.reset((x0b[0] - y0) / ystd, u0n, x0b[0])
     comp_t_log, kms, runtime = _timed_loop(ctrl, dev, Nsim)
-    nfail = ctrl.qp_failures()
-    if nfail:
-        raise _lib.NmpcError("state-feedback NMPC: %d QP solves failed (infeasible hard constraints?)" % nfail)
+    _report_failures(ctrl, what, on_qp_failure)
     L = ctrl.logs
     x_log = L["x_log"].clone(); x_log[:, 0, :] = torch.as_tensor(np.array(x0b[0]), device=dev)
     x_log = x_log.reshape(B, (Nsim + 1) * nx)
@@ -386,32 +411,43 @@ def _state_loop(system, encoder, x_min, x_max, u_min, u_max, x0, Q, R, dt, dlam,
 
 def par_NMPC_linear(system, encoder, x_min, x_max, u_min, u_max, x0, u_ref, Q, R, dt, dlam, stages, x_reference_list,
                     Nc=5, Nsim=30, max_iterations=1, *, tol=1e-5, rho=10000.0, noise=None, C=(0.0, 1.0), targets=None,
-                    return_controller=False):
+                    return_controller=False, as_written=False, return_status=False, on_qp_failure="warn"):
     """State-feedback LPV-NMPC tracking the targets of getXsUs (NMPC.py:507-650), batched:
     x_reference_list [B, nx, >= Nsim+Nc] (or [nx, ...] for one controller), physical units; row 1 is the
     tracked output (NMPC.py:539-540).  Soft state/input box through one slack (weight 10000).  u_ref is
     accepted and unused, as in the reference.  Returns the reference's 9-tuple (x_log, u_log, e_log,
-    comp_t_log, t, runtime, lpv_counter, reference_list_normalized, components_time)."""
+    comp_t_log, t, runtime, lpv_counter, reference_list_normalized, components_time), plus the int8 status log
+    [B, Nsim] with return_status=True.
+    as_written=False (default): input targets follow the step (Us = us[k : k+Nc]) and the linear cost term is
+    2 (Gamma' Omega (Phi x0 - Xs) - Psi Us), as output_NMPC_linear has them for the same step (NMPC_test.py:152,213)
+    - the controller the reference's later code converged on.  as_written=True: NMPC.py:580 (Us = us[:Nc] at every
+    step) and NMPC.py:591 (+ Psi' Us) to the letter.  Both keep the nu-wide shift of the input warm start."""
     out, kms, ctrl = _state_loop(system, encoder, x_min, x_max, u_min, u_max, x0, Q, R, dt, dlam, stages,
-                                 x_reference_list, Nc, Nsim, max_iterations, tol, rho, False, noise, C, targets)
+                                 x_reference_list, Nc, Nsim, max_iterations, tol, rho, False, noise, C, targets,
+                                 as_written=as_written, on_qp_failure=on_qp_failure, what="par_NMPC_linear")
     components_time = np.zeros((4, Nsim * max_iterations))              # NMPC.py:560; column k*max_iterations = step k
     components_time[0, ::max_iterations] = kms[:, 0] * 1e-3
     components_time[1, ::max_iterations] = kms[:, 1] * 1e-3
     components_time[3, ::max_iterations] = kms[:, 2] * 1e-3
     components_time[2, ::max_iterations] = np.maximum(out[3] - kms.sum(1) * 1e-3, 0.0)
     res = tuple(out) + (components_time,)
+    if return_status:
+        res = res + (ctrl.logs["qp_status"][0] if out[1].dim() == 1 else ctrl.logs["qp_status"],)
     return (res, ctrl) if return_controller else res
 
 
 def NMPC_linear(system, encoder, x_min, x_max, u_min, u_max, x0, u_ref, Q, R, dt, dlam, stages, x_reference_list=None,
-                Nc=5, Nsim=30, max_iterations=5, *, tol=1e-7, noise=None, return_controller=False):
+                Nc=5, Nsim=30, max_iterations=5, *, tol=1e-7, noise=None, return_controller=False, return_status=False,
+                on_qp_failure="warn"):
     """State-feedback LPV-NMPC regulating to the origin with hard state/input constraints
     (NMPC.py:374-505; its QP goes to quadprog, the dual active-set method this library implements;
     at most 5 passes, stop 1e-7).  x0 [nx] or [B, nx] (all rows equal).  Returns the reference's 9-tuple
     (x_log, u_log, e_log, comp_t_log, t, runtime, lpv_counter, reference_list_normalized,
-    components_total_time[4])."""
+    components_total_time[4]), plus the int8 status log with return_status=True.  A controller whose hard-constrained
+    QP is infeasible in some step holds its previous plan there (status 2); on_qp_failure "warn" | "raise" | "ignore"."""
     out, kms, ctrl = _state_loop(system, encoder, x_min, x_max, u_min, u_max, x0, Q, R, dt, dlam, stages, None, Nc,
-                                 Nsim, max_iterations, tol, 1.0, True, noise, (0.0, 1.0), None)
+                                 Nsim, max_iterations, tol, 1.0, True, noise, (0.0, 1.0), None,
+                                 on_qp_failure=on_qp_failure, what="NMPC_linear")
     if x_reference_list is not None:                                    # NMPC.py:391 (returned, not tracked)
         nm = encoder.norm
         y0 = np.asarray(nm.y0v if hasattr(nm, "y0v") else nm.y0, np.float64)
@@ -420,4 +456,6 @@ def NMPC_linear(system, encoder, x_min, x_max, u_min, u_max, x0, u_ref, Q, R, dt
     tot = kms.sum(0) * 1e-3
     components_total_time = np.array([tot[0], tot[1], max(out[3].sum() - tot.sum(), 0.0), tot[2]])   # NMPC.py:423
     res = tuple(out) + (components_total_time,)
+    if return_status:
+        res = res + (ctrl.logs["qp_status"][0] if out[1].dim() == 1 else ctrl.logs["qp_status"],)
     return (res, ctrl) if return_controller else res

@@ -210,7 +210,9 @@ def output_nmpc_linear(model, u_min, u_max, y_min, y_max, x0, Q, R, dt, stages, 
 # (NMPC_test.py) does for the same step:
 #   - input targets follow the step, Us = us[k : k+Nc]  (NMPC.py:580 always takes the first Nc);
 #   - linear cost term 2 (Gamma' Omega (Phi x0 - Xs) - Psi Us)  (NMPC.py:591 adds Psi' Us);
+#     (both of these are restored by as_written=True: the fixed window us[:Nc] and + Psi' Us to the letter)
 #   - the input warm start shifts by nu  (NMPC.py:495,640 shift it by nx);
+#   - the last scheduling state after the shift is the predicted x_Nc  (NMPC.py:638 repeats x_{Nc-1});
 def target_selector_state(model, y_ref_norm, Nsim, u_min, u_max, x_min, x_max, C, nodes, weights,
                           f0=None, h0=0.0, max_lpv=10, tol=1e-5, lam=100.0, as_executed=True):
     """mpcUtil.py:167-239 getXsUs: steady states with box constraints on (xs, us), fixed output
@@ -253,13 +255,14 @@ def target_selector_state(model, y_ref_norm, Nsim, u_min, u_max, x_min, x_max, C
     return Xs, Us, Es, iters
 
 
-def state_mpc_qp(list_A, list_B, x0, Xs, Us, Psi, Omega, D, E, M, c, Nc, nx, nu, rho):
+def state_mpc_qp(list_A, list_B, x0, Xs, Us, Psi, Omega, D, E, M, c, Nc, nx, nu, rho, as_written=False):
     """Condensed QP of the state-feedback controllers (NMPC.py:446-458, 588-604).  rho = None: hard
-    constraints, variables u (NMPC_linear); otherwise one slack with weight rho on every row."""
+    constraints, variables u (NMPC_linear); otherwise one slack with weight rho on every row.
+    as_written: the linear term of NMPC.py:591, + Psi' Us."""
     Phi = mpcutil.getPhi(list_A, Nc, nx, nu)
     Gamma = mpcutil.getGamma(list_A, list_B, Nc, nx, nu)
     G = 2 * (Psi + Gamma.T @ Omega @ Gamma)
-    F = 2 * (Gamma.T @ Omega @ (Phi @ x0 - Xs) - Psi @ Us)
+    F = 2 * (Gamma.T @ Omega @ (Phi @ x0 - Xs) + (Psi.T @ Us if as_written else -Psi @ Us))
     L = M @ Gamma + E
     hv = c[:, 0] - (D + M @ Phi) @ x0
     if rho is None:
@@ -276,13 +279,14 @@ def state_mpc_qp(list_A, list_B, x0, Xs, Us, Psi, Omega, D, E, M, c, Nc, nx, nu,
 
 def state_nmpc_linear(model, x_min, x_max, u_min, u_max, x0, Q, R, dt, dlam, stages, x_reference_list=None,
                       Nc=5, Nsim=30, max_iterations=1, tol=1e-5, rho=10000.0, noise=None, y0=None, ystd=None,
-                      C=(0.0, 1.0), targets=None):
+                      C=(0.0, 1.0), targets=None, as_written=False):
     """Closed loop with measured state, single controller.
     x_reference_list [nx, >= Nsim+Nc] given: par_NMPC_linear (NMPC.py:507-650; tracking of the targets
     from getXsUs on row 1 of the reference, slack weight rho = 10000, stop 1e-5).
     x_reference_list None: NMPC_linear (NMPC.py:374-505; regulation to the origin, hard constraints:
     pass rho=None, stop 1e-7, at most 5 passes there).
     y0, ystd: state normalisation vectors (norm.y0, norm.ystd of a full-state model); noise [Nsim, nx].
+    as_written: NMPC.py:580 (Us = us[:Nc] at every step) and NMPC.py:591 (+ Psi' Us) as the code has them.
     Returns a dict of logs."""
     nx, nu = model.nx, model.nu
     nodes, weights = lpv.merge_nodes(*lpv.quad_nodes("simpson", stages, dlam))   # lpv_int, NMPC.py:400,533
@@ -311,12 +315,12 @@ def state_nmpc_linear(model, x_min, x_max, u_min, u_max, x0, Q, R, dt, dlam, sta
     lpv_counter = np.zeros(Nsim, int); plan_log = np.zeros((Nsim, Nc))
     for k in range(Nsim):
         Xs = Xs_all[:, k + 1:k + Nc + 1].T.reshape(nx * Nc)
-        Us = Us_all[:, k:k + Nc].T.reshape(Nc * nu)
+        Us = (Us_all[:, :Nc] if as_written else Us_all[:, k:k + Nc]).T.reshape(Nc * nu)
         while True:
             A, B, _ = lpv.embed(model, x.reshape(Nc, nx), u.reshape(Nc, nu), nodes, weights)
             u_old = u.copy()
             u, eps, xpred, _ = state_mpc_qp(A.reshape(Nc * nx, nx), B.reshape(Nc * nx, nu), x[:nx], Xs, Us, Psi, Omega,
-                                            D, E, M, c, Nc, nx, nu, rho)
+                                            D, E, M, c, Nc, nx, nu, rho, as_written=as_written)
             x[nx:] = xpred[:(Nc - 1) * nx]
             lpv_counter[k] += 1
             if lpv_counter[k] >= max_iterations or np.linalg.norm(u - u_old) < tol:

@@ -95,3 +95,23 @@ def padded_disc_model(omodel, seed=5, extra=1):
                 f32(en.b0), f32(en.w2), f32(en.b2), f32(np.concatenate([en.w4, 0.4 * sm(e, 64)], 0)),
                 f32(np.concatenate([en.b4, np.zeros(e)])))
     return Model(f3, h3, e3, u0=omodel.u0, ustd=omodel.ustd, y0=omodel.y0, ystd=omodel.ystd, na=omodel.na, nb=omodel.nb)
+
+
+def narrowed_disc_model(omodel, hidden, alpha=0.5):
+    """The trained disc model with `hidden` < 64 units per layer (the reference trains 32-wide encoders as well:
+    UnbalancedDisc.ipynb, n_nodes_per_layer = 32): every net keeps its first `hidden` units with the output weights
+    scaled by alpha, and its linear part is re-fitted so that value and Jacobian at the origin are those of the
+    trained net - the closed loop then behaves like the trained one near the origin while the nonlinear branch
+    carries real numbers through every kernel."""
+    import numpy as np
+    from oracle.model import Model, ResNet
+    f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+
+    def narrow(net):
+        k = np.arange(hidden)
+        br = ResNet(np.zeros_like(net.lin_w), np.zeros_like(net.lin_b), f32(net.w0[k]), f32(net.b0[k]), f32(net.w2[np.ix_(k, k)]),
+                    f32(net.b2[k]), f32(alpha * net.w4[:, k]), np.zeros_like(net.b4))
+        z0 = np.zeros(net.n_in)
+        return ResNet(f32(net.jac(z0) - br.jac(z0)), f32(net(z0) - br(z0)), br.w0, br.b0, br.w2, br.b2, br.w4, br.b4)
+    return Model(narrow(omodel.fn), narrow(omodel.hn), narrow(omodel.enc), omodel.u0, omodel.ustd, omodel.y0, omodel.ystd,
+                 omodel.na, omodel.nb)

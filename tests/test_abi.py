@@ -26,7 +26,25 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(h, n), "%s not exported" % n
     assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
-    assert _lib.lib().nmpc_version() >= 100
+    # the library, the header and the ctypes mirror of nmpc_ctrl_config describe the same version / layout
+    hdr = open(os.path.join(ROOT, "include", "nmpc_amd.h")).read()
+    assert _lib.lib().nmpc_version() == int(re.search(r"#define NMPC_AMD_VERSION (\d+)", hdr).group(1))
+
+
+def test_ctrl_config_mirror_matches_the_header(tmp_path):
+    """sizeof(nmpc_ctrl_config) as a C compiler sees the header == the ctypes structure (nmpc_ctrl_create checks
+    struct_size against the library's own sizeof)."""
+    import subprocess
+    from nmpc_amd import _lib
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "nmpc_amd.h"\nint main(void){printf("%zu %zu %zu\\n", '
+                   'sizeof(nmpc_ctrl_config), offsetof(nmpc_ctrl_config, as_written), offsetof(nmpc_ctrl_config, lam));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    size, off_aw, off_lam = map(int, subprocess.check_output([str(exe)]).split())
+    assert size == ctypes.sizeof(_lib.CtrlConfig)
+    assert off_aw == _lib.CtrlConfig.as_written.offset and off_lam == _lib.CtrlConfig.lam.offset
+    assert _lib.CtrlConfig().struct_size == size
 
 
 def test_quad_nodes_host_entry_point_matches_oracle():

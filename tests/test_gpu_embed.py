@@ -416,3 +416,57 @@ def test_embedding_kernel_variants_on_the_trained_model(omodel, tmp_path):
             e = np.abs(d[k].astype(np.float64) - ref[k].astype(np.float64)).max() / scale[k]
             assert e < 2e-6, (name, k, e)
     print("worst error against the oracle per variant:", {n: max(v for (m, _), v in worst.items() if m == n) for n in variants})
+
+
+@pytest.mark.parametrize("nx,H", [(2, 16), (2, 32), (3, 48), (4, 32), (2, 65), (2, 96), (8, 65)])
+def test_hidden_widths_off_the_kernel_sizes(nx, H):
+    """Hidden widths the kernels are not laid out for: below 64 (the reference trains a 32-wide encoder,
+    UnbalancedDisc.ipynb; CasADiExp takes any width, mpcUtil.py:6-31) the nets are padded with zero units to 64 and
+    run on the 64-wide kernels, 65..127 are padded to 128 on the panel kernel.  Same bar as every other width;
+    f(0,0) / h(0) of the padded model are the oracle's."""
+    import nmpc_amd
+    from oracle.model import Model
+    om = Model.synthetic(nx, 1, 1, H, seed=13)
+    params = {k: [np.asarray(a, np.float32) for a in n.params()] for k, n in (("fn", om.fn), ("hn", om.hn))}
+    enc = nmpc_amd.Encoder(params, device="cuda:0")
+    assert enc.hidden == H and np.abs(enc.f0 - om.f0).max() < 1e-12 and np.abs(enc.h0 - om.h0).max() < 1e-12
+    rng = np.random.default_rng(H)
+    for P in (1, 129):
+        x = f32(rng.uniform(-2, 2, (P, nx))); u = f32(rng.uniform(-2, 2, (P, 1))); xc = f32(rng.uniform(-2, 2, (P, nx)))
+        lam, w = nmpc_amd.quad_nodes("simpson", 20)
+        A, B, C = nmpc_amd.embed(enc, torch.tensor(x), torch.tensor(u), torch.tensor(xc), lam, w)
+        Ao, Bo, Co = olpv.embed(om, x, u, *olpv.merge_nodes(*olpv.quad_nodes("simpson", 20)), xc=xc)
+        for got, ref in ((A, Ao), (B, Bo), (C, Co)):
+            err = np.abs(got.cpu().numpy().astype(np.float64).reshape(ref.shape) - ref).max()
+            assert err / np.abs(ref).max() < TOL, (nx, H, P, err / np.abs(ref).max())
+
+
+@pytest.mark.parametrize("nx,H", [(3, 128), (8, 256)])
+def test_panel_kernel_out_of_range_and_huge_bias(nx, H):
+    """The panel kernel scales its fp16 operands towards the top of the fp16 range with bounds taken from the weights
+    alone (worst-case L1 norms), so no input may overflow them: scheduling points hundreds of standard deviations out
+    (every unit saturated somewhere on the lambda-path), a layer-1 bias of +-60 (units pinned unless the input is
+    enormous) and ordinary points in the same launch, against the fp64 oracle at the panel kernel's bar."""
+    import nmpc_amd
+    from oracle.model import Model
+    om = Model.synthetic(nx, 1, 1, H, seed=17)
+    om.fn.b0[5] = 60.0; om.fn.b0[H - 3] = -60.0; om.hn.b0[9] = -60.0
+    om = Model(om.fn, om.hn, None)
+    params = {k: [np.asarray(a, np.float32) for a in n.params()] for k, n in (("fn", om.fn), ("hn", om.hn))}
+    enc = nmpc_amd.Encoder(params, device="cuda:0")
+    rng = np.random.default_rng(3)
+    P = 96
+    x = f32(rng.uniform(-2, 2, (P, nx))); u = f32(rng.uniform(-2, 2, (P, 1))); xc = f32(rng.uniform(-2, 2, (P, nx)))
+    x[16:32] *= 400.0; u[16:32] *= 400.0; xc[16:32] *= 400.0          # a whole workgroup far out
+    x[40] *= 1500.0; xc[41] *= 1500.0; u[70] *= 3000.0                  # single points among ordinary ones
+    x[48:64] *= 60.0; xc[48:64] *= 60.0                                 # lam * W0 z sweeps through the pinned units' biases
+    lam, w = nmpc_amd.quad_nodes("simpson", 20)
+    A, B, C = nmpc_amd.embed(enc, torch.tensor(x), torch.tensor(u), torch.tensor(xc), lam, w)
+    assert torch.isfinite(A).all() and torch.isfinite(B).all() and torch.isfinite(C).all()
+    Ao, Bo, Co = olpv.embed(om, x, u, *olpv.merge_nodes(*olpv.quad_nodes("simpson", 20)), xc=xc)
+    worst = 0.0
+    for got, ref in ((A, Ao), (B, Bo), (C, Co)):
+        err = np.abs(got.cpu().numpy().astype(np.float64).reshape(ref.shape) - ref).max() / np.abs(ref).max()
+        worst = max(worst, err)
+        assert err < 5e-6, err              # (2.4e-6 observed at H = 128; ordinary points: 8e-7; the bar is 1e-5)
+    print("panel kernel, nx %d H %d, out-of-range points and pinned units: worst error %.2e of the matrix scale" % (nx, H, worst))

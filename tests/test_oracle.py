@@ -250,7 +250,15 @@ def test_recorded_closed_loop_of_the_reference(omodel):
     references/randomLevelTime25_30Range-1_1Nsim500.npy.  The script that wrote them is not in the
     repository (settings and solver tolerances unknown), so this is a loose pin: with the canonical
     configuration (NMPC_test.py:324-365) the oracle agrees with the record within 5e-3 (y) and 2e-2
-    (u) wherever the loop has settled on a level, and within 6e-3 in the median over the whole run."""
+    (u) wherever the loop has settled on a level, and within 6e-3 in the median over the whole run.
+    Around the level changes the two differ by up to 0.26 rad and 2.4 V, and no setting of this controller removes
+    that: the record is not a run of output_NMPC_linear - the reference's script plots `y_log - log_q` as a curve of
+    its own, labelled "LPV-NMPC" (NMPC_test.py:422-443), i.e. log_q / log_w hold ANOTHER controller's trajectory on
+    the same reference, kept for comparison (the Ipopt-based NMPC of NMPC.py:33-372, out of scope here, is the only
+    other controller in the repository that tracks an output reference with preview).  Both settle on the same
+    levels because model, plant and reference are the same; their transients are different controllers'.  The
+    record that IS this controller's - Experiments/lpv_counter.npy - is reproduced step for step below.  The
+    unmasked difference is asserted against a loose bound only so that a gross change shows."""
     import os
     from conftest import GOLDEN
     from oracle.nmpc import output_nmpc_linear
@@ -262,6 +270,8 @@ def test_recorded_closed_loop_of_the_reference(omodel):
     assert np.median(np.abs(y - q)) < 6e-3 and np.median(np.abs(o["u_log"] - w)) < 3e-2
     idx = recorded_run_windows(r[1], 450)
     assert len(idx) >= 50 and np.abs(y[idx] - q[idx]).max() < 5e-3 and np.abs(o["u_log"][idx] - w[idx]).max() < 2e-2
+    print("recorded run, all 450 samples: max |y - log_q| %.3f, max |u - log_w| %.3f" % (np.abs(y - q).max(), np.abs(o["u_log"] - w).max()))
+    assert np.abs(y - q).max() < 0.3 and np.abs(o["u_log"] - w).max() < 2.6
 
 
 def test_recorded_pass_counters_of_the_reference(omodel):
