@@ -47,8 +47,11 @@ FP32_MFMA_PEAK_TFLOPS = 157.3
 FP16_MFMA_PEAK_TFLOPS = 16 * FP32_MFMA_PEAK_TFLOPS
 SPLIT_PRODUCTS = 3
 HBM_PEAK_GBS = 8000.0
-EVENT_EVERY = 8            # HIP event pairs bracket the launches of every 8th timed step
-REPEATS = 3                # the K-step timed region is run this many times; `value` is the first
+FP64_PEAK_TFLOPS = 78.6    # MI355X fp64 (vector = matrix rate; datasheet figure, the microarchitecture notes list none)
+EVENT_EVERY = 2            # the instrumented region brackets the launches of every 2nd step with HIP event pairs
+INSTRUMENTED_STEPS = 64    # steps of the instrumented region (run after the timed regions; never part of `value`)
+REPEATS = 3                # the K-step timed region is run this many times, event-free; `value` is the first
+PROFILES = os.path.join(ROOT, "profiles")
 
 CONFIGS = {
     "cfg2": dict(Nc=10, ubox=(-4.0, 4.0), ybox=(-1.2, 1.2), sigma=0.0, max_it=4, tol=1e-1, batch=4096, scaling="weak"),
@@ -190,22 +193,57 @@ def spawn_ranks(n, argv):
     return rc if rc >= 0 else 1
 
 
-def isolated_embed_tflops(nmpc_amd, enc, lam, w, npts, dev, reps=10):
-    """One full embedding pass (npts scheduling points) alone on the current stream, event-timed."""
+def isolated_embed_tflops(nmpc_amd, enc, lam, w, npts, dev, reps=20, batches=5):
+    """One full embedding pass (npts scheduling points) alone on the current stream: `batches` event-timed runs
+    of `reps` back-to-back launches each, after a warm-up of the same length; returns (median, all) in TFLOP/s."""
     import torch
     g = torch.Generator().manual_seed(7)
     x = (torch.rand(npts, 2, generator=g) * 2 - 1).to(dev)
     u = (torch.rand(npts, 1, generator=g) * 2 - 1).to(dev)
     xc = (torch.rand(npts, 2, generator=g) * 2 - 1).to(dev)
-    for _ in range(3):
-        nmpc_amd.embed(enc, x, u, xc, lam, w)
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
+    A = torch.empty(npts, 2, 2, device=dev); B = torch.empty(npts, 2, 1, device=dev); C = torch.empty(npts, 1, 2, device=dev)
     for _ in range(reps):
-        nmpc_amd.embed(enc, x, u, xc, lam, w)
-    b.record()
-    torch.cuda.synchronize(dev)
-    return NODES_EVALUATED * FLOPS_PER_POINT_NODE * npts / (a.elapsed_time(b) / reps * 1e-3) / 1e12
+        nmpc_amd.embed(enc, x, u, xc, lam, w, out=(A, B, C))
+    res = []
+    for _ in range(batches):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            nmpc_amd.embed(enc, x, u, xc, lam, w, out=(A, B, C))
+        b.record()
+        torch.cuda.synchronize(dev)
+        res.append(NODES_EVALUATED * FLOPS_PER_POINT_NODE * npts / (a.elapsed_time(b) / reps * 1e-3) / 1e12)
+    return float(np.median(res)), res
+
+
+def pmc_traffic(name):
+    """HBM traffic per launch of a kernel from the committed PMC summary profiles/<name> (written by
+    tools/pmc_summary.py --json from separate rocprofv3 --pmc passes of this command): FETCH_SIZE and WRITE_SIZE
+    are in KB; on gfx950 FETCH_SIZE counts a wide coalesced read at half its bytes, so it is doubled."""
+    path = os.path.join(PROFILES, name)
+    try:
+        d = json.load(open(path))
+        fetch, write = d["FETCH_SIZE"]["mean"] * 1024.0, d["WRITE_SIZE"]["mean"] * 1024.0
+    except (OSError, KeyError, ValueError):
+        return None, None
+    return 2.0 * fetch + write, {"source": "profiles/" + name, "fetch_size_kb_raw": d["FETCH_SIZE"]["mean"],
+                                 "write_size_kb": d["WRITE_SIZE"]["mean"], "launches": d["FETCH_SIZE"]["n"],
+                                 "correction": "traffic = 2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE reports half "
+                                               "the bytes of wide coalesced reads); per launch, averaged over the launches "
+                                               "of the profiled run"}
+
+
+def wide_solve_flops(Nc, nx=2):
+    """fp64 flops of one long-horizon condense + QP solve with an empty working set (n = Nc + 1 variables,
+    2 Nc + 1 row pairs): Gamma recurrences, G = Gamma' Omega Gamma over the lower block triangle, Cholesky of G,
+    the transform L^-1 [pair normals], prediction; active-set iterations add 4 n (n + pairs) each."""
+    n, pairs = Nc + 1, 2 * Nc + 1
+    gam = Nc * (Nc + 1) / 2 * 2 * nx * nx
+    hess = sum((a + 1) * (Nc - a) for a in range(Nc)) * (2 * nx * nx + 4 * nx)
+    chol = n ** 3 / 3.0
+    trans = n * n * pairs
+    pred = Nc * (Nc + 1) / 2 * 2 * nx
+    return gam + hess + chol + trans + pred, 4.0 * n * (n + pairs)
 
 
 def solve_bytes_per_controller_pass(Nc, nx=2):
@@ -225,7 +263,8 @@ def closed_loop_bench(args, cfgname, rank, world, dev, shard):
     K, W = args.steps, args.warmup
     LAT = max(0, args.latency_steps)
     R = max(1, args.repeats)
-    nsim = W + R * K + LAT
+    KI = 0 if args.no_kernel_events else max(0, min(args.instrumented_steps, K))
+    nsim = W + R * K + KI + LAT
     if cfg["scaling"] == "weak":
         B = args.batch or cfg["batch"]
         lo = rank * B
@@ -266,11 +305,9 @@ def closed_loop_bench(args, cfgname, rank, world, dev, shard):
 
     ctrl.run(0, W)                                   # untimed warm-up steps
     torch.cuda.synchronize(dev)
-    every = 0 if args.no_kernel_events else max(1, args.event_every)
+    every = 0 if not KI else max(1, args.event_every)
     region_ms = []
-    prof = None
-    for r in range(R):                               # region 0 is the reported one
-        ctrl.profile(every if r == 0 else 0)         # HIP event pairs around the launches of steps k % every == 0
+    for r in range(R):                               # region 0 is the reported one; no events, no stamps in any of them
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -280,13 +317,29 @@ def closed_loop_bench(args, cfgname, rank, world, dev, shard):
         if world > 1:
             dist.barrier()
         region_ms.append((time.perf_counter() - t0) * 1e3)
-        if r == 0:
-            prof = ctrl.profile_read()
-            ctrl.profile(False)
     elapsed = region_ms[0] * 1e-3
+    # instrumented region (separate from the timed ones): HIP event pairs on the launch streams around the launches
+    # of every `every`-th step, and the embedding workgroups stamp the shader clock they ran at
+    k_inst0 = W + R * K
+    prof = {"embed": (0, 0.0), "solve": (0, 0.0), "plant": (0, 0.0)}
+    inst_ms, clock_ghz = None, None
+    if KI:
+        ctrl.profile(every)
+        stamp_ok = NC < 24 and cfg["max_it"] >= 1
+        if stamp_ok:
+            ctrl.embed_clock(True)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        ctrl.run(k_inst0, KI)
+        torch.cuda.synchronize(dev)
+        inst_ms = (time.perf_counter() - t0) * 1e3
+        prof = ctrl.profile_read()
+        ctrl.profile(False)
+        if stamp_ok:
+            clock_ghz = ctrl.embed_clock(False)
     # per-step latency: one step of the whole batch at a time, host-synchronised (not part of `value`)
     lat = []
-    for k in range(W + R * K, W + R * K + LAT):
+    for k in range(W + R * K + KI, W + R * K + KI + LAT):
         t1 = time.perf_counter()
         ctrl.run(k, 1)
         torch.cuda.synchronize(dev)
@@ -314,8 +367,9 @@ def closed_loop_bench(args, cfgname, rank, world, dev, shard):
         sys.stderr.write("  %-16s %8.0f %8.0f %8.0f   iterations mean %.2f; clock %.2f GHz\n" % ("kernel", np.median(tot_c), tot_c.mean(), tot_c.max(), st[:, 10].mean(),
                          np.median((st[:, 9] - st[:, 0]) / np.maximum(st[:, 11], 1)) * 0.1))
     qp_fail, qp_solves, qp_iters = ctrl.stats()
-    if qp_fail:
-        raise SystemExit("QP failures in the closed loop: result invalid")
+    failed_steps = int((ctrl.logs["qp_status"] != 0).sum().item())      # (controller, step) pairs that held their plan
+    if qp_fail > 0.01 * max(qp_solves, 1):
+        raise SystemExit("%d of %d QP solves failed in the closed loop: result invalid" % (qp_fail, qp_solves))
 
     region_max = [shard.reduce_stats([m], "max")[0] for m in region_ms]
     elapsed_max = region_max[0] * 1e-3
@@ -333,43 +387,68 @@ def closed_loop_bench(args, cfgname, rank, world, dev, shard):
     assert gathered["y_log"].shape[0] == int(tot_ctrl)
     value = tot_ctrl * K / elapsed_max
     n_launch, ms_embed = prof["embed"]
-    sampled = [k - W for k in range(W, W + K) if every and k % every == 0]
+    sampled = [k for k in range(k_inst0, k_inst0 + KI) if every and k % every == 0]
     if n_launch == 0 or not sampled:
         n_launch, ms_embed, sampled = 0, float("nan"), []
     # algorithmic flops of the event-bracketed launches: passes of this rank in the sampled steps
     fpp = NODES_EVALUATED * FLOPS_PER_POINT_NODE
     # (passes from tail_from on run in the per-controller tail launch, which is timed with the solves)
-    wide = lpv if not ctrl.tail_from else torch.clamp(lpv, max=ctrl.tail_from)
-    embed_flops = fpp * NC * float(wide[:, sampled].sum().item()) if sampled else float("nan")
-    iso = isolated_embed_tflops(nmpc_amd, enc, lam, w, B * NC, dev)
+    lpv_all = ctrl.logs["lpv_counter"]
+    wide = lpv_all if not ctrl.tail_from else torch.clamp(lpv_all, max=ctrl.tail_from)
+    embed_points = NC * float(wide[:, sampled].sum().item()) if sampled else float("nan")
+    embed_flops = fpp * embed_points
+    iso, iso_all = isolated_embed_tflops(nmpc_amd, enc, lam, w, B * NC, dev)
+    lpv = lpv_all[:, W:W + K]
     y = gathered["y_log"][:B, W + 1:W + K + 1]
     track = float((y - torch.clamp(torch.as_tensor(refs[:, W:W + K], device=dev), ylo, yhi)).abs().median().item())
     peak = FP16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS
     achieved = embed_flops / (ms_embed * 1e-3) / 1e12
     n_solve, ms_solve = prof["solve"]
+    traffic, traffic_src = pmc_traffic("r3_pmc_embed_loop.json" if NC < 24 else "r3_cfg3_pmc_embed.json")
+    # algorithmic HBM bytes of a launch: 5 fp32 in, 8 fp32 out per scheduling point (x, u, xc; A, B, C) + both packed nets once
+    alg_bytes = 52.0 * embed_points / max(n_launch, 1) + 2 * 21024 * 4
     roof_embed = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                  "traffic": None,
-                  "traffic_note": "not measured in this run; PMC passes of the same command are under profiles/ "
-                                  "(r2c_pmc_embed_loop.txt: FETCH_SIZE + WRITE_SIZE ~1.0 MB of HBM traffic per launch, weights and points)",
-                  "peak_note": "dense f16 MFMA peak (16 x 157.3) / 3 products per f32 product; achieved = algorithmic f32 "
+                  "traffic": traffic, "traffic_detail": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
+                  "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
+                  "peak_note": "dense f16 MFMA peak (16 x 157.3 at 2.4 GHz) / 3 products per f32 product; achieved = algorithmic f32 "
                                "flops of the %d nodes the kernel evaluates (the lambda = 0 node of the 41 is a host "
-                               "constant) / event-timed launch span; launches of different slices overlap each other" % NODES_EVALUATED,
-                  "achieved_isolated": iso, "frac_isolated": iso / peak,
+                               "constant) / event-timed launch span in the instrumented region; launches of different "
+                               "slices overlap each other, so in-loop spans are an upper bound of the kernel's own time" % NODES_EVALUATED,
+                  "clock_ghz_sustained": clock_ghz,
+                  "frac_at_sustained_clock": (achieved / (peak * clock_ghz / 2.4)) if clock_ghz else None,
+                  "clock_note": "median over the workgroups of the instrumented region's first-pass launches of "
+                                "(shader-clock cycles) / (100 MHz real-time ticks) between workgroup start and end; peak assumes 2.4 GHz",
+                  "achieved_isolated": iso, "frac_isolated": iso / peak, "achieved_isolated_runs": iso_all,
+                  "isolated_note": "one full pass (%d points) alone on the GPU: median of 5 runs of 20 back-to-back launches" % (B * NC),
                   "achieved_over_wall": fpp * NC * passes / elapsed_max / 1e12,
                   "frac_of_f32_mfma_peak_isolated": iso / FP32_MFMA_PEAK_TFLOPS,
                   "kernel": "embed_kernel", "launches": n_launch, "avg_launch_ms": ms_embed / max(n_launch, 1),
                   "flops_per_launch": embed_flops / max(n_launch, 1)}
-    solve_passes = float(lpv[:, sampled].sum().item()) if sampled else float("nan")
-    sb = solve_bytes_per_controller_pass(NC)
-    ach_s = sb * solve_passes / (ms_solve * 1e-3) / 1e9 if n_solve else float("nan")
-    roof_solve = {"bound": "hbm", "achieved": ach_s, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_s / HBM_PEAK_GBS,
-                  "traffic": None, "kernel": "mpc_solve_wide_kernel" if NC >= 24 else "mpc_solve_kernel", "launches": n_solve,
-                  "avg_launch_ms": ms_solve / max(n_solve, 1), "bytes_per_controller_pass": sb,
-                  "note": "condense + QP + prediction, one %s per controller, everything between A/B/C and the "
-                          "plan stays in LDS/registers: latency-bound, HBM traffic is the algorithmic minimum%s"
-                          % ("workgroup of four wavefronts" if NC >= 24 else "wavefront",
-                             "; launches include the per-controller tail launch (passes >= %d: embedding + solve in one kernel)"
-                             % (ctrl.tail_from + 1) if ctrl.tail_from else "")}
+    solve_passes = float(lpv_all[:, sampled].sum().item()) if sampled else float("nan")
+    if NC >= 24:
+        # the long-horizon solve is dense fp64 linear algebra: priced against the fp64 rate
+        f_solve, f_iter = wide_solve_flops(NC)
+        its = qp_iters / max(qp_solves, 1)
+        ach_s = (f_solve + its * f_iter) * solve_passes / (ms_solve * 1e-3) / 1e12 if n_solve else float("nan")
+        tr_s, tr_s_src = pmc_traffic("r3_cfg3_pmc_solve.json")
+        roof_solve = {"bound": "mfma", "pipe": "fp64", "achieved": ach_s, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                      "frac": ach_s / FP64_PEAK_TFLOPS, "traffic": tr_s, "traffic_detail": tr_s_src,
+                      "kernel": "mpc_solve_wide_kernel", "launches": n_solve, "avg_launch_ms": ms_solve / max(n_solve, 1),
+                      "flops_per_solve": f_solve + its * f_iter, "flops_per_launch": (f_solve + its * f_iter) * solve_passes / max(n_solve, 1),
+                      "note": "condense + QP + prediction of one controller per workgroup of four wavefronts, fp64: "
+                              "Gamma recurrences, Hessian, Cholesky, transform of the constraint normals, active-set iterations "
+                              "(%.2f per solve); algorithmic flops / event-timed launch span against the MI355X fp64 rate" % its}
+    else:
+        sb = solve_bytes_per_controller_pass(NC)
+        ach_s = sb * solve_passes / (ms_solve * 1e-3) / 1e9 if n_solve else float("nan")
+        tr_s, tr_s_src = pmc_traffic("r3_pmc_solve.json")
+        roof_solve = {"bound": "hbm", "achieved": ach_s, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_s / HBM_PEAK_GBS,
+                      "traffic": tr_s, "traffic_detail": tr_s_src, "kernel": "mpc_solve_kernel", "launches": n_solve,
+                      "avg_launch_ms": ms_solve / max(n_solve, 1), "bytes_per_controller_pass": sb,
+                      "note": "condense + QP + prediction, one wavefront per controller, everything between A/B/C and the "
+                              "plan stays in LDS/registers: latency-bound, HBM traffic is the algorithmic minimum%s"
+                              % ("; launches include the per-controller tail launch (passes >= %d: embedding + solve in one kernel)"
+                                 % (ctrl.tail_from + 1) if ctrl.tail_from else "")}
     dominant_solve = n_solve and ms_solve > ms_embed
     res = {
         "metric": "closed-loop NMPC controller-steps/sec (B=4096, N=10)" if cfgname == "cfg2" else
@@ -388,15 +467,21 @@ def closed_loop_bench(args, cfgname, rank, world, dev, shard):
         "n_ranks_seen": int(round(n_ranks_seen)),
         "ms_per_step_repeats": [m / K for m in region_max],
         "ms_per_step_spread": {"min": min(region_max) / K, "median": float(np.median(region_max)) / K, "max": max(region_max) / K,
-                               "note": "%d back-to-back timed regions of %d steps each; value / ms_per_step are region 0" % (R, K)},
+                               "note": "%d back-to-back timed regions of %d steps each, none of them instrumented; value / "
+                                       "ms_per_step are region 0" % (R, K)},
+        "instrumented_region": None if not KI else {
+            "steps": KI, "ms_per_step": inst_ms / KI, "event_every": every,
+            "note": "run after the timed regions, not part of value: HIP event pairs on the launch streams around every "
+                    "launch of every %d-th step, embedding workgroups stamp their clock; roofline figures come from here" % every},
+        "qp_failed_solves": int(qp_fail), "qp_failed_controller_steps": failed_steps,
         "p50_step_latency_ms": p50_latency,
         "mean_lpv_passes_per_step": tot_passes / (tot_ctrl * K),
         "mean_qp_active_set_iterations": qp_iters / max(qp_solves, 1),
         "kernel_ms_per_step": {k: prof[k][1] / max(len(sampled), 1) for k in prof},
         "launches_per_step": sum(prof[k][0] for k in prof) / max(len(sampled), 1),
-        "kernel_ms_note": "HIP event pairs on %d of the %d timed steps; launches of different slices of the "
-                          "batch run concurrently on separate streams, so these spans overlap and their sum "
-                          "exceeds ms_per_step" % (len(sampled), K),
+        "kernel_ms_note": "HIP event pairs on %d of the %d steps of the instrumented region; launches of different "
+                          "slices of the batch run concurrently on separate streams, so these spans overlap and their sum "
+                          "exceeds ms_per_step" % (len(sampled), KI),
         "target_selector_s": t_targets, "final_gather_s": t_gather,
         "median_abs_tracking_error": track,
         "roofline": roof_solve if dominant_solve else roof_embed,
@@ -515,7 +600,9 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="diagnostic: record no HIP event pairs (roofline fields become null)")
     ap.add_argument("--event-every", type=int, default=EVENT_EVERY,
-                    help="bracket the kernel launches of every n-th timed step with HIP event pairs")
+                    help="bracket the kernel launches of every n-th step of the instrumented region with HIP event pairs")
+    ap.add_argument("--instrumented-steps", type=int, default=INSTRUMENTED_STEPS,
+                    help="steps of the instrumented region that follows the timed regions (at most --steps; 0: none)")
     ap.add_argument("--cpu-controllers", type=int, default=64)
     ap.add_argument("--cpu-steps", type=int, default=12, help="steps per controller of the 1-thread slice baseline")
     ap.add_argument("--cpu-steps-mt", type=int, default=120, help="steps per controller of the all-threads slice baseline")

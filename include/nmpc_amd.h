@@ -192,6 +192,12 @@ int nmpc_ctrl_profile_read(nmpc_ctrl* c, int* launches, double* total_ms, void* 
 /* Same record, per step: ms[nsteps][3] = summed launch durations of steps k0 .. k0+nsteps-1 per kind
  * (the getAB / solve / sim buckets of the reference's components_time, NMPC_test.py:152-300). */
 int nmpc_ctrl_profile_read_steps(nmpc_ctrl* c, int k0, int nsteps, double* ms, void* stream);
+/* Diagnostics: the clock the chip holds under the embedding kernel.  With `stamps` set (device memory, 2 * slots
+ * 64-bit words), every workgroup b of the first-pass embedding launches of later nmpc_ctrl_run calls stores the
+ * shader-clock cycles and the 100 MHz real-time ticks it lived for to stamps[2 (b % slots)], [.. + 1] (64-wide
+ * split-fp16 kernel only); cycles / ticks * 0.1 is the clock in GHz.  NULL (the default) switches it off; no stamp
+ * instruction executes then. */
+int nmpc_ctrl_set_embed_stamps(nmpc_ctrl* c, unsigned long long* stamps, int slots);
 /* The LPV re-scheduling loop of a step (NMPC_test.py:154-260) runs its first passes as batch-wide launches and,
  * for the canonical shapes, the remaining ones in one per-controller launch: returns the first pass (0-based) that
  * runs there, 0 if none does.  Launches of that kernel are timed with kind 1. */

@@ -64,6 +64,7 @@ SIGNATURES = {
     "nmpc_ctrl_tail_from": (ctypes.c_int, [c_void_p]),
     "nmpc_ctrl_stats": (ctypes.c_int, [c_void_p, ctypes.POINTER(ctypes.c_longlong), c_void_p]),
     "nmpc_ctrl_set_status_log": (ctypes.c_int, [c_void_p, c_void_p]),
+    "nmpc_ctrl_set_embed_stamps": (ctypes.c_int, [c_void_p, c_void_p, ctypes.c_int]),
 }
 
 MAX_NODES = 256

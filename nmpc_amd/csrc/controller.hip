@@ -440,6 +440,8 @@ struct nmpc_ctrl {
     ModelDev m;
     NodeTable nt;
     MpcGeom g;
+    unsigned long long* embed_stamps = nullptr;   // diagnostics (nmpc_ctrl_set_embed_stamps)
+    int embed_stamp_slots = 0;
     signed char* qp_status_log = nullptr;   // caller's per-step status log (nmpc_ctrl_set_status_log), may be null
     int tail_from = 0;                // LPV passes from this one on run in the per-controller tail kernel (0: none do)
     std::vector<void*> allocs;
@@ -674,6 +676,7 @@ extern "C" int nmpc_ctrl_run(nmpc_ctrl* c, int k0, int nsteps, const double* Xs,
                 if (d.c.mode == 0) { a.xc = d.xc32; a.C = d.C32; }
                 a.npts = d.B * d.Nc; a.group = d.Nc;
                 if (it > 0) { a.count_dev = d.nact + it; a.act = d.act + (size_t)it * d.B; }
+                else if (c->embed_stamps) { a.stamps = c->embed_stamps; a.stamp_slots = c->embed_stamp_slots; }   // first passes only
                 ProfRec pr;
                 bool on = prof_begin(c, 0, k, s, pr);
                 if (embed_launch_prepared(c->m, a, c->nt, s, true)) return 1;
@@ -722,6 +725,12 @@ extern "C" int nmpc_ctrl_run(nmpc_ctrl* c, int k0, int nsteps, const double* Xs,
 extern "C" int nmpc_ctrl_set_status_log(nmpc_ctrl* c, signed char* qp_status_log) {
     NMPC_REQUIRE(c, "nmpc_ctrl_set_status_log: null argument");
     c->qp_status_log = qp_status_log;
+    return 0;
+}
+
+extern "C" int nmpc_ctrl_set_embed_stamps(nmpc_ctrl* c, unsigned long long* stamps, int slots) {
+    NMPC_REQUIRE(c && (stamps == nullptr || slots >= 1), "nmpc_ctrl_set_embed_stamps: bad argument");
+    c->embed_stamps = stamps; c->embed_stamp_slots = stamps ? slots : 0;
     return 0;
 }
 

@@ -38,6 +38,10 @@ struct EmbedArgs {
     const int* act;        // optional active-group list: point p -> row act[p/group]*group + p%group
     int group;
     int n_ftiles;
+    // optional diagnostics (split-fp16 kernel): workgroup b stores the shader-clock cycles and the 100 MHz
+    // real-time ticks it lived for to stamps[2 (b % stamp_slots)], [.. + 1]; null in every production launch
+    unsigned long long* stamps;
+    int stamp_slots;
 };
 
 int embed_launch(const ModelDev& m, EmbedArgs a, const NodeTable& nt, hipStream_t stream, bool loop = false);

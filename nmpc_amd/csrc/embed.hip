@@ -204,6 +204,8 @@ __global__ __launch_bounds__(EMBED_THREADS, 3) void embed_kernel(EmbedArgs a, No
     int npts = a.npts;
     if (a.count_dev) npts = min(npts, *a.count_dev * a.group);
     const int b = blockIdx.x;
+    unsigned long long c0 = 0, r0 = 0;
+    if (a.stamps) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }   // diagnostics only
     if (b < a.n_ftiles) {
         if (b * EMBED_TILE >= npts) return;
         if constexpr (MODE == 0) embed_tile<NX, NU, NX>(a.fpack, lds, a.x, a.u, a.A, a.B, b, npts, a.act, a.group, nt);
@@ -213,6 +215,13 @@ __global__ __launch_bounds__(EMBED_THREADS, 3) void embed_kernel(EmbedArgs a, No
         if (t * EMBED_TILE >= npts) return;
         if constexpr (MODE == 0) embed_tile<NX, 0, NY>(a.hpack, lds, a.xc, nullptr, a.C, nullptr, t, npts, a.act, a.group, nt);
         else embed_tile_h2<NX, 0, NY, MODE == 2>(a.hpack, lds, a.xc, nullptr, a.C, nullptr, t, npts, a.act, a.group, nt);
+    }
+    if (a.stamps) {
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0) {
+            unsigned long long* st = a.stamps + 2 * (size_t)(b % a.stamp_slots);
+            st[0] = c1 - c0; st[1] = r1 - r0;
+        }
     }
 }
 

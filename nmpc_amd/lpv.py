@@ -54,24 +54,32 @@ def _f32(t, model, last):
     return t.contiguous()
 
 
-def embed(model, x=None, u=None, xc=None, lam=None, w=None):
+def embed(model, x=None, u=None, xc=None, lam=None, w=None, out=None):
     """A, B at (x, u) and/or C at xc for arbitrary leading batch dims; returns (A, B, C) with
-    None for the parts not requested."""
+    None for the parts not requested.  out: optional (A, B, C) fp32 device tensors to write into (entries for
+    parts not requested are ignored), for callers that keep their buffers across calls."""
     lam = np.ascontiguousarray(lam, np.float32); w = np.ascontiguousarray(w, np.float32)
     A = B = C = None
     npts = None
+
+    def _buf(i, shape):
+        if out is None or out[i] is None:
+            return torch.empty(shape, device=model.device, dtype=torch.float32)
+        t = out[i]
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == int(np.prod(shape)) and t.device == model.device
+        return t
     if x is not None:
         x = _f32(x, model, model.nx); u = _f32(u, model, model.nu)
         u = u.expand(x.shape[:-1] + (model.nu,)).contiguous() if u.shape[:-1] != x.shape[:-1] else u
         npts = x.numel() // model.nx
-        A = torch.empty(x.shape[:-1] + (model.nx, model.nx), device=model.device, dtype=torch.float32)
-        B = torch.empty(x.shape[:-1] + (model.nx, model.nu), device=model.device, dtype=torch.float32)
+        A = _buf(0, x.shape[:-1] + (model.nx, model.nx))
+        B = _buf(1, x.shape[:-1] + (model.nx, model.nu))
     if xc is not None:
         xc = _f32(xc, model, model.nx)
         nc = xc.numel() // model.nx
         assert npts is None or nc == npts, "x and xc must hold the same number of points"
         npts = nc
-        C = torch.empty(xc.shape[:-1] + (model.ny, model.nx), device=model.device, dtype=torch.float32)
+        C = _buf(2, xc.shape[:-1] + (model.ny, model.nx))
     with torch.cuda.device(model.device):
         rc = lib().nmpc_lpv_embed(model.handle, npts, ptr(x), ptr(u), ptr(xc),
                                   lam.ctypes.data_as(_lib.c_float_p), w.ctypes.data_as(_lib.c_float_p), lam.size,

@@ -199,6 +199,24 @@ class Controller:
             check(lib().nmpc_ctrl_profile_read(self.handle, n, ms, current_stream()), "nmpc_ctrl_profile_read")
         return {k: (int(n[i]), float(ms[i])) for i, k in enumerate(("embed", "solve", "plant"))}
 
+    def embed_clock(self, enable=True, slots=8192):
+        """Diagnostics: enable=True makes the first-pass embedding launches of later run() calls stamp their
+        workgroups' lifetimes in shader-clock cycles and 100 MHz ticks; enable=False stops that and returns the
+        median clock in GHz over the workgroups stamped since (None if none were)."""
+        if enable:
+            self._stamps = torch.zeros(slots, 2, dtype=torch.int64, device=self.encoder.device)
+            check(lib().nmpc_ctrl_set_embed_stamps(self.handle, ptr(self._stamps), slots), "nmpc_ctrl_set_embed_stamps")
+            return None
+        check(lib().nmpc_ctrl_set_embed_stamps(self.handle, None, 0), "nmpc_ctrl_set_embed_stamps")
+        st = getattr(self, "_stamps", None)
+        if st is None:
+            return None
+        torch.cuda.synchronize(self.encoder.device)
+        v = st.cpu().numpy().astype(np.float64)
+        v = v[v[:, 1] > 0]
+        self._stamps = None
+        return float(np.median(v[:, 0] / v[:, 1]) * 0.1) if len(v) else None
+
     @property
     def tail_from(self):
         """First LPV pass (0-based) that runs in the per-controller tail launch; 0 if every pass is a batch-wide launch."""
