@@ -474,6 +474,7 @@ def closed_loop_bench(args, cfgname, rank, world, dev, shard):
             "note": "run after the timed regions, not part of value: HIP event pairs on the launch streams around every "
                     "launch of every %d-th step, embedding workgroups stamp their clock; roofline figures come from here" % every},
         "qp_failed_solves": int(qp_fail), "qp_failed_controller_steps": failed_steps,
+        "qp_solves": int(qp_solves), "qp_solves_by_the_full_active_set_kernel": int(getattr(ctrl, "slow_solves", 0)),
         "p50_step_latency_ms": p50_latency,
         "mean_lpv_passes_per_step": tot_passes / (tot_ctrl * K),
         "mean_qp_active_set_iterations": qp_iters / max(qp_solves, 1),

@@ -176,8 +176,9 @@ int nmpc_ctrl_run(nmpc_ctrl* c, int k0, int nsteps, const double* Xs, const doub
  * (device, int8; 0 = all solves of the step succeeded) by later nmpc_ctrl_run calls; the other controllers of the
  * batch are not affected.  NULL (the default) switches the log off. */
 int nmpc_ctrl_set_status_log(nmpc_ctrl* c, signed char* qp_status_log);
-/* stats[3] (host): [0] (controller, pass) QP solves since reset that did not return status 0,
- * [1] QP solves, [2] active-set iterations summed over them.  Synchronises the stream. */
+/* stats[4] (host): [0] (controller, pass) QP solves since reset that did not return status 0,
+ * [1] QP solves, [2] active-set iterations summed over them, [3] (long horizons) solves that the first-stage
+ * kernel handed to the full active-set kernel.  Synchronises the stream. */
 int nmpc_ctrl_stats(nmpc_ctrl* c, long long* stats, void* stream);
 
 /* Optional per-kernel timing of a controller's launches with HIP events recorded on the stream the

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(64 * PLANT_WAVES) void plant_kernel(CtrlDev d, RunP
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int b = blockIdx.x * PLANT_WAVES + wv;
     if (blockIdx.x == 0 && threadIdx.x == 0)
-        for (int it = 1; it <= d.maxit; ++it) d.nact[it] = 0;
+        for (int it = 0; it <= d.maxit; ++it) { if (it) d.nact[it] = 0; if (d.nslow) d.nslow[it] = 0; }
     if (b >= d.B) return;
     double* in = sm[wv]; double* t1s = sm[wv] + MAX_HIST;
     const int Nc = d.Nc;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void plant_model_kernel(CtrlDev d, RunPtrs rp,
     __shared__ double in[16], outv[8], t1s[256], t2s[256];
     const int tid = threadIdx.x, b = blockIdx.x;
     if (b == 0 && tid == 0)
-        for (int it = 1; it <= d.maxit; ++it) d.nact[it] = 0;
+        for (int it = 0; it <= d.maxit; ++it) { if (it) d.nact[it] = 0; if (d.nslow) d.nslow[it] = 0; }
     const int Nc = d.Nc, H = d.hidden, ns = d.n_sim;
     double* up = d.uplan + (size_t)b * Nc;
     double* xpd = d.xpred + (size_t)b * Nc * NX;
@@ -259,7 +259,7 @@ template <int NX>
 __global__ void plant_state_kernel(CtrlDev d, RunPtrs rp, int k) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b == 0)
-        for (int it = 1; it <= d.maxit; ++it) d.nact[it] = 0;
+        for (int it = 0; it <= d.maxit; ++it) { if (it) d.nact[it] = 0; if (d.nslow) d.nslow[it] = 0; }
     if (b >= d.B) return;
     const int Nc = d.Nc, ns = d.n_sim;
     double* up = d.uplan + (size_t)b * Nc;
@@ -309,8 +309,8 @@ template <int NX>
 __global__ void reset_kernel(CtrlDev d, double u0n, State8 x0s, double pw, double pth) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b == 0) {
-        for (int i = 0; i < (d.maxit + 2) * MAX_SLICES; ++i) d.nact[i] = 0;
-        *d.qp_fail = 0ull;
+        for (int i = 0; i < (d.maxit + 2) * MAX_SLICES; ++i) { d.nact[i] = 0; if (d.nslow) d.nslow[i] = 0; }
+        d.qp_fail[0] = 0ull; d.qp_fail[1] = 0ull;
     }
     if (b >= d.B) return;
     const double* x0 = x0s.v;
@@ -533,7 +533,7 @@ extern "C" int nmpc_ctrl_create(nmpc_ctrl** out, const nmpc_model* m, const nmpc
     rc |= alloc((void**)&d.xp, sb * 2 * 8); rc |= alloc((void**)&d.uhist, sb * (d.na > 0 ? d.na : 1) * 8);
     rc |= alloc((void**)&d.yhist, sb * (d.nyh > 0 ? d.nyh : 1) * 8); rc |= alloc((void**)&d.eps, sb * 8);
     rc |= alloc((void**)&d.cnt, sb * 4); rc |= alloc((void**)&d.act, sb * (d.maxit + 1) * 4);
-    rc |= alloc((void**)&d.nact, (size_t)(d.maxit + 2) * MAX_SLICES * 4); rc |= alloc((void**)&d.qp_fail, 8); rc |= alloc((void**)&d.qp_stat, sb * 8);
+    rc |= alloc((void**)&d.nact, (size_t)(d.maxit + 2) * MAX_SLICES * 4); rc |= alloc((void**)&d.qp_fail, 16); rc |= alloc((void**)&d.qp_stat, sb * 8);
     rc |= alloc((void**)&d.qp_worst, sb * 4);
     rc |= alloc((void**)&d.xs32, sb * Nc * nx * 4); rc |= alloc((void**)&d.us32, sb * Nc * 4);
     rc |= alloc((void**)&d.xc32, sb * Nc * nx * 4); rc |= alloc((void**)&d.A32, sb * Nc * nx * nx * 4);
@@ -541,6 +541,7 @@ extern "C" int nmpc_ctrl_create(nmpc_ctrl** out, const nmpc_model* m, const nmpc
     if (mpc_wide_applies(Nc, nx, d.c.mode, d.c.slack)) {
         // long-horizon kernels carry each controller's working set from one QP solve to the next
         rc |= alloc((void**)&d.wset, sb * 64); rc |= alloc((void**)&d.wcnt, sb * 4);
+        rc |= alloc((void**)&d.slow, sb * (d.maxit + 1) * 4); rc |= alloc((void**)&d.nslow, (size_t)(d.maxit + 2) * MAX_SLICES * 4);
         const char* e = getenv("NMPC_QP_WARM");
         d.warm = e ? atoi(e) : 2;          // 0 cold starts, 1 warm-started iteration, 2 verified fast path first
         if (d.warm < 0 || d.warm > 2) d.warm = 2;
@@ -579,6 +580,7 @@ extern "C" int nmpc_ctrl_create(nmpc_ctrl** out, const nmpc_model* m, const nmpc
         sl.d.xs32 += o * Nc * nx; sl.d.us32 += o * Nc; sl.d.xc32 += o * Nc * nx;
         sl.d.A32 += o * Nc * nx * nx; sl.d.B32 += o * Nc * nx; sl.d.C32 += o * Nc * nx;
         if (d.wset) { sl.d.wset += o * 64; sl.d.wcnt += o; }
+        if (d.slow) { sl.d.slow += o * (d.maxit + 1); sl.d.nslow += (size_t)(d.maxit + 2) * i; }
         if (d.stamps) sl.d.stamps += o * 16;
         if (ns > 1) {
             if (hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess ||
@@ -772,12 +774,12 @@ extern "C" int nmpc_ctrl_profile_read_steps(nmpc_ctrl* c, int k0, int nsteps, do
 
 extern "C" int nmpc_ctrl_stats(nmpc_ctrl* c, long long* qp_fail, void* stream) {
     NMPC_REQUIRE(c && qp_fail, "nmpc_ctrl_stats: null argument");
-    unsigned long long v = 0;
+    unsigned long long v[2] = {0, 0};
     std::vector<unsigned> st(2 * (size_t)c->d.B);
-    NMPC_HIP_CHECK(hipMemcpyAsync(&v, c->d.qp_fail, 8, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    NMPC_HIP_CHECK(hipMemcpyAsync(v, c->d.qp_fail, 16, hipMemcpyDeviceToHost, (hipStream_t)stream));
     NMPC_HIP_CHECK(hipMemcpyAsync(st.data(), c->d.qp_stat, st.size() * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
     NMPC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
-    qp_fail[0] = (long long)v; qp_fail[1] = 0; qp_fail[2] = 0;
+    qp_fail[0] = (long long)v[0]; qp_fail[1] = 0; qp_fail[2] = 0; qp_fail[3] = (long long)v[1];
     for (int b = 0; b < c->d.B; ++b) { qp_fail[1] += st[2 * b]; qp_fail[2] += st[2 * b + 1]; }
     return 0;
 }

@@ -337,6 +337,9 @@ struct CtrlDev {
     // state (fp64)
     double *x0n, *xpred, *uplan, *ymeas, *xp, *uhist, *yhist, *eps;
     int *cnt, *act, *nact;
+    // long-horizon solve in two stages: controllers the first-stage kernel leaves undecided, per pass
+    // (slow[it * B + ..], nslow[it]); null when that kernel is not used
+    int *slow, *nslow;
     unsigned long long* qp_fail;   // failed solves
     unsigned* qp_stat;             // [B][2]: solves, active-set iterations per controller
     int* qp_worst;                 // [B]: worst QP status among the passes of the current step (cleared by the plant kernels)

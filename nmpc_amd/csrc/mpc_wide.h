@@ -35,6 +35,7 @@
 namespace nmpc {
 
 constexpr int WIDE_THREADS = 256;
+constexpr int WIDE_SLOW_GRID = 256;   // workgroups that walk the slow list (one per CU is resident)
 
 __host__ __device__ inline int wide_npairs(int Nc) { return 2 * Nc + 1; }
 // Columns of the pair table: the pairs, then the linear term; padded to 16 mod 32 so that the two lanes of a
@@ -43,24 +44,29 @@ __host__ __device__ inline int wide_cols(int Nc) { return ((wide_npairs(Nc) + 1 
 // instantiated: nx = 2 with KH 16 / 25 / 32 (horizons to 32 / 50 / 63), nx = 3, 4 with KH 32
 __host__ __device__ inline int wide_kh(int Nc, int nx) { return nx != 2 ? 32 : (Nc <= 32 ? 16 : (Nc <= 50 ? 25 : 32)); }
 
+// doubles of scratch wide_hessian needs
+__host__ __device__ inline int wide_hessian_scratch(int Nc, int nx) { return 4 * Nc * nx * nx; }
+
 struct WideLds {
-    double *Lm, *Lw, *Mi, *Al, *Gam, *Ak, *Bk, *Ck, *qd, *xi, *x0, *Xs, *Us, *uold, *hv, *invdL, *invdW, *Dp, *usol, *wbuf, *red;
+    double *Lm, *Lw, *Mi, *Al, *Pm, *sseg, *Ak, *Bk, *Ck, *qd, *xi, *x0, *Xs, *Us, *uold, *hv, *invdL, *invdW, *Dp, *usol, *wbuf, *red;
     int* Wtab;
-    // The factor of the Hessian and Gamma (condensing, transform, recovery of z, prediction) and the working-set
-    // Gram matrix and inverse factor (active-set iteration only) are never live together: they share one region,
-    // and the former sit in registers while the iteration runs (wide_solve).
+    // The factor of the Hessian (transform, recovery of z) and the working-set Gram matrix and inverse factor
+    // (active-set iteration only) are never live together: they share one region, and the former sits in registers
+    // while the iteration runs (wide_solve).  Pm: the prefix products P_m = A_m .. A_1 (P_0 = I), from which every
+    // block of Gamma follows as Gamma_{i,j} = P_{i-j} B_j (mpcUtil.py:93-104) - Gamma itself is never formed.
     __host__ __device__ static int shared_doubles(int Nc, int nx, int KH) {
-        const int n = Nc + 1, a = 2 * KH * Nc + Nc * (Nc + 1) / 2 * nx, b = 2 * n * n;
+        const int n = Nc + 1, a = 2 * KH * Nc, b = 2 * n * n;
         return a > b ? a : b;
     }
     __host__ __device__ static int doubles(int Nc, int nx, int KH) {
         const int n = Nc + 1, NPc = wide_cols(Nc), R = 2 * KH;
-        return shared_doubles(Nc, nx, KH) + R * NPc + Nc * nx * nx + 5 * Nc * nx + 4 + 2 * Nc + 2 * wide_npairs(Nc) + 2 +
+        return shared_doubles(Nc, nx, KH) + R * NPc + 2 * Nc * nx * nx + wide_hessian_scratch(Nc, nx) + 5 * Nc * nx + 4 + 2 * Nc + 2 * wide_npairs(Nc) + 2 +
                R + n + NPc + n + 3 * 4 * 64 + 64 + 2 * n + 2;
     }
     __device__ void carve(double* p, int Nc, int nx, int KH) {
         const int n = Nc + 1, NPc = wide_cols(Nc), R = 2 * KH;
-        Lm = p; Gam = p + R * Nc; Lw = p; Mi = p + n * n; p += shared_doubles(Nc, nx, KH); Al = p; p += R * NPc;
+        Lm = p; Lw = p; Mi = p + n * n; p += shared_doubles(Nc, nx, KH); Al = p; p += R * NPc;
+        Pm = p; p += Nc * nx * nx; sseg = p; p += 4 * Nc * nx * nx;
         Ak = p; p += Nc * nx * nx; Bk = p; p += Nc * nx; Ck = p; p += Nc * nx; qd = p; p += Nc * nx; xi = p; p += Nc * nx;
         Xs = p; p += Nc * nx; x0 = p; p += 4; Us = p; p += Nc; uold = p; p += Nc; hv = p; p += 2 * wide_npairs(Nc) + 2;
         invdL = p; p += R; invdW = p; p += n; Dp = p; p += NPc; usol = p; p += n; wbuf = p; p += 3 * 4 * 64; red = p; p += 64;
@@ -127,6 +133,217 @@ __device__ __forceinline__ bool wide_chol_regs(double* Lm, double* invd, int n) 
     return ok;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Condensing from the prefix products P_m = A_m .. A_1 (P_0 = I).  The reference's matrices are
+//   Gamma_{i,j} = P_{i-j} B_j,  Phi_i = P_i A_0,  F0_i = (sum_{j<=i} P_j) f0      (mpcUtil.py:84-104, 322-331)
+// so every quantity the QP needs is a sum over LAGS of nx x nx blocks, O(Nc^2) of them instead of the O(Nc^3)
+// block products of forming Gamma' Omega Gamma from Gamma; Gamma is never stored.
+// LT: any struct with the members Pm, Ak, Bk, Ck, qd, xi, x0, Xs, Us, Lm (WideLds, FastLds).
+
+// wave 0 only: Pm and the free response xi_i = P_i A_0 x0 + (sum_{j<=i} P_j) f0 (lane i).  Both are prefix
+// operations over the horizon - an ordered product of nx x nx matrices and a sum of nx-vectors - and run as
+// inclusive scans over the lanes (six doubling rounds) instead of Nc dependent steps.
+template <int NX, class LT>
+__device__ __forceinline__ void wide_prefix(const MpcConst& c, LT& L, int Nc) {
+    constexpr int NN = NX * NX;
+    const int lane = threadIdx.x & 63;
+    double M[NN];                                      // lane m: A_m (m >= 1), the identity on lane 0 and beyond the horizon
+#pragma unroll
+    for (int e = 0; e < NN; ++e) {
+        const double a = L.Ak[(lane >= 1 && lane < Nc ? lane : 0) * NN + e];
+        M[e] = (lane >= 1 && lane < Nc) ? a : ((e / NX == e % NX) ? 1.0 : 0.0);
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {           // lane m: (A_m .. A_{m-off+1}) (A_{m-off} .. ) - later factors on the left
+        double Y[NN], Pn[NN];
+#pragma unroll
+        for (int e = 0; e < NN; ++e) Y[e] = __shfl_up(M[e], off, 64);
+#pragma unroll
+        for (int r = 0; r < NX; ++r)
+#pragma unroll
+            for (int cc = 0; cc < NX; ++cc) {
+                double a = 0.0;
+#pragma unroll
+                for (int l = 0; l < NX; ++l) a = fma(M[r * NX + l], Y[l * NX + cc], a);
+                Pn[r * NX + cc] = a;
+            }
+        if (lane >= off) {
+#pragma unroll
+            for (int e = 0; e < NN; ++e) M[e] = Pn[e];
+        }
+    }
+    if (lane < Nc) {
+#pragma unroll
+        for (int e = 0; e < NN; ++e) L.Pm[lane * NN + e] = M[e];
+    }
+    double w0[NX], sf[NX], v[NX];
+#pragma unroll
+    for (int r = 0; r < NX; ++r) {
+        double a = 0.0;
+#pragma unroll
+        for (int l = 0; l < NX; ++l) a = fma(L.Ak[r * NX + l], L.x0[l], a);
+        w0[r] = a;
+    }
+#pragma unroll
+    for (int r = 0; r < NX; ++r) {
+        double a = 0.0, b2 = 0.0;
+#pragma unroll
+        for (int l = 0; l < NX; ++l) { a = fma(M[r * NX + l], w0[l], a); b2 = fma(M[r * NX + l], c.f0[l], b2); }
+        v[r] = a; sf[r] = b2;
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+        for (int r = 0; r < NX; ++r) { const double y = __shfl_up(sf[r], off, 64); sf[r] += lane >= off ? y : 0.0; }
+    }
+    if (lane < Nc) {
+#pragma unroll
+        for (int r = 0; r < NX; ++r) L.xi[lane * NX + r] = v[r] + sf[r];
+    }
+}
+
+// Whole workgroup (contains barriers).  Hessian, lower triangle into Lm (row-major, ld Nc):
+//   G_ab = 2 (sum_{i>=a} Gamma_{i,a}' Q Gamma_{i,b} + R [a = b]) = 2 (B_a' S(a-b, Nc-1-a) B_b + R [a = b]),
+//   S(d, m) = sum_{m'<=m} P_m'' Q P_{m'+d}.
+// Thread (lag d = lane, quarter = wave) walks a quarter of the lag's range m = 0 .. Nc-1-d, accumulates the running
+// sum from the quarter's start and emits the entry (a, b) = (Nc-1-m, Nc-1-m-d) at every step; the quarters' totals
+// meet in `sseg` and each thread then adds what the earlier quarters contribute to its entries.
+// Linear term F_a = 2 (B_a' sum_m P_m' qd_{a+m} - R Us_a), the same way, handed to put_f(a, F_a).
+template <int NX, class LT, class PutF>
+__device__ __forceinline__ void wide_hessian(const MpcConst& c, LT& L, int Nc, double* sseg, PutF put_f) {
+    constexpr int NN = NX * NX;
+    const int tid = threadIdx.x, d = tid & 63, seg = tid >> 6;
+    const bool lag = d < Nc;
+    const int len = lag ? Nc - d : 0;
+    const int m0 = seg * len / 4, m1 = (seg + 1) * len / 4;
+    const int steps = (Nc + 3) / 4 + 1;                     // uniform bound of m1 - m0
+    double S[NN], f[NX];
+#pragma unroll
+    for (int e = 0; e < NN; ++e) S[e] = 0.0;
+#pragma unroll
+    for (int r = 0; r < NX; ++r) f[r] = 0.0;
+    auto quad = [&](const double* Sx, int a_, int b_) {       // B_a' Sx B_b
+        double g = 0.0;
+#pragma unroll
+        for (int r = 0; r < NX; ++r) {
+            double sb = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < NX; ++cc) sb = fma(Sx[r * NX + cc], L.Bk[b_ * NX + cc], sb);
+            g = fma(L.Bk[a_ * NX + r], sb, g);
+        }
+        return g;
+    };
+#pragma unroll 2
+    for (int st = 0; st < steps; ++st) {
+        const int m = m0 + st;
+        const bool on = m < m1;
+        const int mm = on ? m : 0, md = on ? m + d : 0;
+        double Pq[NN], Pd[NN], QP[NN], qv[NX];
+#pragma unroll
+        for (int e = 0; e < NN; ++e) { Pq[e] = L.Pm[mm * NN + e]; Pd[e] = L.Pm[md * NN + e]; }
+#pragma unroll
+        for (int k = 0; k < NX; ++k) qv[k] = L.qd[md * NX + k];          // (lane a = d of the linear term: i = a + m)
+        if (on) {
+#pragma unroll
+            for (int r = 0; r < NX; ++r)
+#pragma unroll
+                for (int cc = 0; cc < NX; ++cc) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int l = 0; l < NX; ++l) a = fma(c.Q[r * NX + l], Pd[l * NX + cc], a);
+                    QP[r * NX + cc] = a;
+                }
+#pragma unroll
+            for (int r = 0; r < NX; ++r) {
+#pragma unroll
+                for (int cc = 0; cc < NX; ++cc)
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) S[r * NX + cc] = fma(Pq[k * NX + r], QP[k * NX + cc], S[r * NX + cc]);
+#pragma unroll
+                for (int k = 0; k < NX; ++k) f[r] = fma(Pq[k * NX + r], qv[k], f[r]);
+            }
+            const int a_ = Nc - 1 - m, b_ = a_ - d;
+            L.Lm[a_ * Nc + b_] = 2.0 * (quad(S, a_, b_) + (d == 0 ? c.R : 0.0));
+        }
+    }
+    if (lag) {
+#pragma unroll
+        for (int e = 0; e < NN; ++e) sseg[(seg * Nc + d) * NN + e] = S[e];
+    }
+    __syncthreads();
+    if (lag && seg > 0) {
+        double So[NN];
+#pragma unroll
+        for (int e = 0; e < NN; ++e) So[e] = 0.0;
+        for (int s2 = 0; s2 < seg; ++s2)
+#pragma unroll
+            for (int e = 0; e < NN; ++e) So[e] += sseg[(s2 * Nc + d) * NN + e];
+        for (int m = m0; m < m1; ++m) {
+            const int a_ = Nc - 1 - m, b_ = a_ - d;
+            L.Lm[a_ * Nc + b_] += 2.0 * quad(So, a_, b_);
+        }
+    }
+    __syncthreads();                                               // sseg is free again: the linear term's partial sums
+    if (lag) {
+#pragma unroll
+        for (int r = 0; r < NX; ++r) sseg[(seg * Nc + d) * NX + r] = f[r];
+    }
+    __syncthreads();
+    if (tid < Nc) {
+        double fa = 0.0;
+#pragma unroll
+        for (int r = 0; r < NX; ++r) {
+            const double fr = (sseg[(0 * Nc + tid) * NX + r] + sseg[(1 * Nc + tid) * NX + r]) +
+                              (sseg[(2 * Nc + tid) * NX + r] + sseg[(3 * Nc + tid) * NX + r]);
+            fa = fma(L.Bk[tid * NX + r], fr, fa);
+        }
+        put_f(tid, 2.0 * (fa - c.R * L.Us[tid]));
+    }
+}
+
+// entry k of the untransformed normal of pair p: input pairs (p even, p < 2 Nc) are unit vectors, output pair of
+// y_{a+1} is (C_a Gamma_{a,:})' = (C_a P_{a-k} B_k)_k for k <= a; pair 1 (the measured y_0) has no dependence on u
+template <int NX, class LT>
+__device__ __forceinline__ double wide_col_entry(const LT& L, int Nc, int p, int k) {
+    if (!(p & 1) && p < 2 * Nc) return (p >> 1) == k ? 1.0 : 0.0;
+    const int a_ = p == 2 * Nc ? Nc - 1 : (p - 3) / 2;
+    if (p < 3 || k > a_ || k >= Nc) return 0.0;
+    const double* P = L.Pm + (a_ - k) * NX * NX;
+    double cg = 0.0;
+#pragma unroll
+    for (int cc = 0; cc < NX; ++cc) {
+        double vc = 0.0;
+#pragma unroll
+        for (int r = 0; r < NX; ++r) vc = fma(L.Ck[a_ * NX + r], P[r * NX + cc], vc);
+        cg = fma(vc, L.Bk[k * NX + cc], cg);
+    }
+    return cg;
+}
+
+// whole workgroup (contains barriers): x_pred = Phi x0 + Gamma u + F0 into `out` (may be xi itself),
+// x_i = xi_i + sum_{j<=i} P_{i-j} (B_j u_j)
+template <int NX, class LT>
+__device__ __forceinline__ void wide_predict_into(LT& L, int Nc, const double* usol, double* out) {
+    const int tid = threadIdx.x;
+    for (int e = tid; e < Nc * NX; e += WIDE_THREADS) L.qd[e] = L.Bk[e] * usol[e / NX];      // qd is free by now
+    __syncthreads();
+    for (int e = tid; e < Nc * NX; e += WIDE_THREADS) {
+        const int i = e / NX, r = e % NX;
+        double a = L.xi[e];
+#pragma unroll 4
+        for (int j = 0; j <= i; ++j) {
+            const double* P = L.Pm + (i - j) * NX * NX + r * NX;
+#pragma unroll
+            for (int l = 0; l < NX; ++l) a = fma(P[l], L.qd[j * NX + l], a);
+        }
+        out[e] = a;
+    }
+    __syncthreads();
+}
+template <int NX, class LT>
+__device__ __forceinline__ void wide_predict(LT& L, int Nc, const double* usol) { wide_predict_into<NX>(L, Nc, usol, L.xi); }
+
 struct WideDump { double *Ge, *Fe, *Le, *hv; };
 
 // Working set carried from one solve of a controller to its next (row ids 2 pair + sign bit, at most 64):
@@ -150,56 +367,10 @@ __device__ __forceinline__ int wide_solve(const MpcConst& c, WideLds& L, double 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Nc = c.Nc, n = Nc + 1, NP = wide_npairs(Nc), NPc = wide_cols(Nc);
     double* Al = L.Al;
-    // ---- P1: wave 0 runs the condensing recurrences (lane j < Nc: column j of Gamma; lane Nc: free response),
-    //          the other waves clear the pair table, the inverse factor and the padding rows of Lm
+    // ---- P1: wave 0 forms the prefix products and the free response (wide_prefix); the other waves clear the pair
+    //          table, the inverse factor and the padding rows of Lm
     if (wave == 0) {
-        const int j = lane;
-        const bool col = j < Nc, fr = j == Nc;
-        double v[NX], pf[NX], sf[NX];
-#pragma unroll
-        for (int r = 0; r < NX; ++r) { v[r] = col ? L.Bk[j * NX + r] : 0.0; pf[r] = c.f0[r]; sf[r] = c.f0[r]; }
-        if (fr) {
-#pragma unroll
-            for (int r = 0; r < NX; ++r) {
-                double a = 0.0;
-#pragma unroll
-                for (int l = 0; l < NX; ++l) a = fma(L.Ak[r * NX + l], L.x0[l], a);
-                v[r] = a;
-            }
-        }
-        auto emit = [&](int d) {
-            if (col && j + d < Nc) {
-#pragma unroll
-                for (int r = 0; r < NX; ++r) L.Gam[MpcLds::tri(j + d, j) * NX + r] = v[r];
-            }
-            if (fr) {
-#pragma unroll
-                for (int r = 0; r < NX; ++r) L.xi[d * NX + r] = v[r] + sf[r];
-            }
-        };
-        emit(0);
-        double An[NX * NX];
-#pragma unroll
-        for (int e = 0; e < NX * NX; ++e) An[e] = Nc > 1 ? L.Ak[NX * NX + e] : 0.0;
-        for (int d = 1; d < Nc; ++d) {
-            double A[NX * NX];
-#pragma unroll
-            for (int e = 0; e < NX * NX; ++e) A[e] = An[e];
-            const int dn = d + 1 < Nc ? d + 1 : d;           // next step's matrix is in flight during this one
-#pragma unroll
-            for (int e = 0; e < NX * NX; ++e) An[e] = L.Ak[dn * NX * NX + e];
-            double nv[NX], np[NX];
-#pragma unroll
-            for (int r = 0; r < NX; ++r) {
-                double a = 0.0, b2 = 0.0;
-#pragma unroll
-                for (int l = 0; l < NX; ++l) { a = fma(A[r * NX + l], v[l], a); b2 = fma(A[r * NX + l], pf[l], b2); }
-                nv[r] = a; np[r] = b2;
-            }
-#pragma unroll
-            for (int r = 0; r < NX; ++r) { v[r] = nv[r]; pf[r] = np[r]; sf[r] += np[r]; }
-            emit(d);
-        }
+        wide_prefix<NX>(c, L, Nc);
     } else {
         const int t3 = tid - 64, n3 = WIDE_THREADS - 64;
         for (int e = t3; e < R * NPc; e += n3) Al[e] = 0.0;
@@ -220,37 +391,19 @@ __device__ __forceinline__ int wide_solve(const MpcConst& c, WideLds& L, double 
     if (tid < Nc) Al[tid * NPc + 2 * tid] = 1.0;             // pair 2 i: the bounds on u_i, a = e_i
     __syncthreads();
     WIDE_STAMP(2);
-    // ---- P3: Hessian (lower triangle), linear term, output-row coefficients: one item per pair (a, b <= a)
-    const int items = Nc * (Nc + 1) / 2;
-    for (int t = tid; t < items; t += WIDE_THREADS) {
-        int a_ = (int)((__builtin_sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-        while ((a_ + 1) * (a_ + 2) / 2 <= t) ++a_;
-        while (a_ * (a_ + 1) / 2 > t) --a_;
-        const int b_ = t - a_ * (a_ + 1) / 2;
-        double g = 0.0, f = 0.0;
-        int ta = MpcLds::tri(a_, a_), tb = MpcLds::tri(a_, b_);
-#pragma unroll 4
-        for (int i = a_; i < Nc; ++i) {
-            double ga[NX], gb[NX];
-#pragma unroll
-            for (int r = 0; r < NX; ++r) { ga[r] = L.Gam[ta * NX + r]; gb[r] = L.Gam[tb * NX + r]; }
-#pragma unroll
-            for (int r = 0; r < NX; ++r) {
-                double qg = 0.0;
-#pragma unroll
-                for (int l = 0; l < NX; ++l) qg = fma(c.Q[r * NX + l], gb[l], qg);
-                g = fma(ga[r], qg, g);
-                f = fma(ga[r], L.qd[i * NX + r], f);
-            }
-            ta += i + 1; tb += i + 1;
+    // ---- P3: Hessian (lower triangle) and linear term from the prefix products (wide_hessian), then the
+    //          output-row coefficients C_a Gamma_{a,b} = C_a P_{a-b} B_b, one item per pair (a, b <= a)
+    wide_hessian<NX>(c, L, Nc, L.sseg, [&](int a_, double fv) { Al[a_ * NPc + NP] = fv; });
+    {
+        const int items = Nc * (Nc + 1) / 2;
+        for (int t = tid; t < items; t += WIDE_THREADS) {
+            int a_ = (int)((__builtin_sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+            while ((a_ + 1) * (a_ + 2) / 2 <= t) ++a_;
+            while (a_ * (a_ + 1) / 2 > t) --a_;
+            const int b_ = t - a_ * (a_ + 1) / 2;
+            const int pair = a_ + 1 < Nc ? 2 * (a_ + 1) + 1 : 2 * Nc;      // y_{a+1}: rows -/+ of block a+1; y_Nc last
+            Al[b_ * NPc + pair] = wide_col_entry<NX>(L, Nc, pair, b_);
         }
-        L.Lm[a_ * Nc + b_] = 2.0 * (g + (a_ == b_ ? c.R : 0.0));
-        if (a_ == b_) Al[a_ * NPc + NP] = 2.0 * (f - c.R * L.Us[a_]);
-        double cg = 0.0;
-#pragma unroll
-        for (int r = 0; r < NX; ++r) cg = fma(L.Ck[a_ * NX + r], L.Gam[MpcLds::tri(a_, b_) * NX + r], cg);
-        const int pair = a_ + 1 < Nc ? 2 * (a_ + 1) + 1 : 2 * Nc;      // y_{a+1}: rows -/+ of block a+1; y_Nc last
-        Al[b_ * NPc + pair] = cg;
     }
     __syncthreads();
     WIDE_STAMP(3);
@@ -578,10 +731,10 @@ __device__ __forceinline__ int wide_solve(const MpcConst& c, WideLds& L, double 
         }
         WIDE_STAMP(6);
         // ---- P8: dual active-set iteration
-        // The factor of G and Gamma move to registers for the duration of the iteration; their LDS becomes the
-        // working set's Gram matrix and inverse factor.
-        constexpr int SAVE_N = (R * R + R * (R + 1) / 2 * NX + WIDE_THREADS - 1) / WIDE_THREADS;
-        const int save_len = R * Nc + Nc * (Nc + 1) / 2 * NX;
+        // The factor of G moves to registers for the duration of the iteration; its LDS becomes the working set's
+        // Gram matrix and inverse factor.
+        constexpr int SAVE_N = (R * R + WIDE_THREADS - 1) / WIDE_THREADS;
+        const int save_len = R * Nc;
         double saved[SAVE_N];
         __syncthreads();
 #pragma unroll
@@ -817,14 +970,7 @@ __device__ __forceinline__ int wide_solve(const MpcConst& c, WideLds& L, double 
     __syncthreads();
     WIDE_STAMP(8);
     // ---- P10: x_pred = Phi x0 + Gamma u + F0 (into xi)
-    for (int e = tid; e < Nc * NX; e += WIDE_THREADS) {
-        const int i = e / NX, r = e % NX;
-        double a = L.xi[e];
-#pragma unroll 4
-        for (int j = 0; j <= i; ++j) a = fma(L.Gam[MpcLds::tri(i, j) * NX + r], L.usol[j], a);
-        L.xi[e] = a;
-    }
-    __syncthreads();
+    wide_predict<NX>(L, Nc, L.usol);
     WIDE_STAMP(9);
     if (st && tid == 0) { st[10] = (unsigned long long)iters | ((unsigned long long)fast_why << 32); st[11] = __builtin_amdgcn_s_memrealtime() - rt0; }
 #undef WIDE_STAMP
@@ -862,13 +1008,11 @@ __global__ __launch_bounds__(WIDE_THREADS) void mpc_qp_wide_kernel(MpcQpArgs a) 
     }
 }
 
+// One LPV pass of controller b by the whole workgroup.  try_fast: first try the controller's carried working set as
+// a whole (off when the first-stage kernel of mpc_wide_fast.h has already done so).
 template <int NX, int KH>
-__global__ __launch_bounds__(WIDE_THREADS) void mpc_solve_wide_kernel(CtrlDev d, RunPtrs rp, int it, int k) {
-    extern __shared__ __align__(16) double mpc_lds[];
-    const int gid = blockIdx.x, tid = threadIdx.x;
-    const int count = it == 0 ? d.B : min(d.nact[it], d.B);
-    if (gid >= count) return;
-    const int b = it == 0 ? gid : d.act[(size_t)it * d.B + gid];
+__device__ __forceinline__ void wide_ctrl_pass(const CtrlDev& d, const RunPtrs& rp, int it, int k, int b, double* mpc_lds, bool try_fast) {
+    const int tid = threadIdx.x;
     const int Nc = d.Nc, ntot = d.n_sim + Nc;
     unsigned long long* stp = d.stamps ? d.stamps + (size_t)b * 16 : nullptr;
     if (stp && tid == 0) stp[12] = __builtin_amdgcn_s_memtime();
@@ -915,7 +1059,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void mpc_solve_wide_kernel(CtrlDev d,
         if (r1 >= 0 && pos1 < 64) wl[pos1] = (unsigned char)r1;
         int tot = c0 + __popcll(m1);
         tot = tot > Nc + 1 ? Nc + 1 : tot;
-        warm.in = wl; warm.n_in = d.warm ? tot : 0; warm.out = ws; warm.n_out = d.wcnt + b; warm.fast = d.warm >= 2;
+        warm.in = wl; warm.n_in = d.warm ? tot : 0; warm.out = ws; warm.n_out = d.wcnt + b; warm.fast = d.warm >= 2 && try_fast;
     }
     __syncthreads();
     int qp_it = 0;
@@ -959,6 +1103,20 @@ __global__ __launch_bounds__(WIDE_THREADS) void mpc_solve_wide_kernel(CtrlDev d,
     if (stp && tid == 0) { stp[13] = __builtin_amdgcn_s_memtime(); stp[14] = (unsigned long long)it; }
 }
 
+// slow_mode 0: the controllers of pass `it` (all of them in pass 0, the work list afterwards), one per workgroup.
+// slow_mode 1: the controllers the first-stage kernel left undecided (slow[it][..], nslow[it]); a small grid
+// walks the list, because a workgroup of this kernel needs most of a CU's LDS even if it only comes to exit.
+template <int NX, int KH>
+__global__ __launch_bounds__(WIDE_THREADS) void mpc_solve_wide_kernel(CtrlDev d, RunPtrs rp, int it, int k, int slow_mode) {
+    extern __shared__ __align__(16) double mpc_lds[];
+    const int count = slow_mode ? min(d.nslow[it], d.B) : (it == 0 ? d.B : min(d.nact[it], d.B));
+    for (int gid = blockIdx.x; gid < count; gid += gridDim.x) {
+        const int b = slow_mode ? d.slow[(size_t)it * d.B + gid] : (it == 0 ? gid : d.act[(size_t)it * d.B + gid]);
+        wide_ctrl_pass<NX, KH>(d, rp, it, k, b, mpc_lds, slow_mode == 0);
+        __syncthreads();                             // the LDS is reused by the next controller
+    }
+}
+
 // host side (mpc_wide.hip, mpc_wide34.hip)
 bool mpc_wide_applies(int Nc, int nx, int mode, int slack);
 int launch_mpc_qp_wide(const MpcQpArgs& a, hipStream_t s);
@@ -987,7 +1145,9 @@ static int launch_solve_wide_t(const CtrlDev& d, const RunPtrs& rp, int it, int 
         mark_used_on_device(once);
     }
     const size_t lds = sizeof(double) * (size_t)WideLds::doubles(d.Nc, NX, KH);
-    hipLaunchKernelGGL((mpc_solve_wide_kernel<NX, KH>), dim3(d.B), dim3(WIDE_THREADS), lds, s, d, rp, it, k);
+    const int slow_mode = (d.warm >= 2 && d.slow) ? 1 : 0;       // the first-stage kernel has run: only its leftovers
+    const int grid = slow_mode ? (d.B < WIDE_SLOW_GRID ? d.B : WIDE_SLOW_GRID) : d.B;
+    hipLaunchKernelGGL((mpc_solve_wide_kernel<NX, KH>), dim3(grid), dim3(WIDE_THREADS), lds, s, d, rp, it, k, slow_mode);
     NMPC_HIP_CHECK(hipGetLastError());
     return 0;
 }

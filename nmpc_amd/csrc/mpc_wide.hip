@@ -2,7 +2,7 @@
 // for nx = 2 (nx = 3, 4: mpc_wide34.hip).
 #include <cstdlib>
 
-#include "mpc_wide.h"
+#include "mpc_wide_fast.h"
 
 namespace nmpc {
 
@@ -31,12 +31,15 @@ int launch_mpc_qp_wide(const MpcQpArgs& a, hipStream_t s) {
     return launch_qp_wide_t<2, 32>(a, s);
 }
 
+// Two stages when the carried working sets are tried first (NMPC_QP_WARM = 2, the default): the small-LDS kernel that
+// decides the common case, then the full kernel over what it left (mpc_wide_fast.h).
 int launch_mpc_solve_wide(const CtrlDev& d, const RunPtrs& rp, int it, int k, hipStream_t s) {
     if (d.nx != 2) return launch_mpc_solve_wide_nx34(d, rp, it, k, s);
     const int kh = wide_kh(d.Nc, 2);
-    if (kh == 16) return launch_solve_wide_t<2, 16>(d, rp, it, k, s);
-    if (kh == 25) return launch_solve_wide_t<2, 25>(d, rp, it, k, s);
-    return launch_solve_wide_t<2, 32>(d, rp, it, k, s);
+    const bool two = d.warm >= 2 && d.slow;
+    if (kh == 16) return (two && launch_solve_fast_t<2, 16>(d, rp, it, k, s)) ? 1 : launch_solve_wide_t<2, 16>(d, rp, it, k, s);
+    if (kh == 25) return (two && launch_solve_fast_t<2, 25>(d, rp, it, k, s)) ? 1 : launch_solve_wide_t<2, 25>(d, rp, it, k, s);
+    return (two && launch_solve_fast_t<2, 32>(d, rp, it, k, s)) ? 1 : launch_solve_wide_t<2, 32>(d, rp, it, k, s);
 }
 
 }  // namespace nmpc

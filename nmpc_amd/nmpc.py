@@ -233,9 +233,10 @@ class Controller:
 
     def stats(self):
         """(failed QP solves, QP solves, active-set iterations) since reset; synchronises."""
-        v = (ctypes.c_longlong * 3)()
+        v = (ctypes.c_longlong * 4)()
         with torch.cuda.device(self.encoder.device):
             check(lib().nmpc_ctrl_stats(self.handle, v, current_stream()), "nmpc_ctrl_stats")
+        self.slow_solves = int(v[3])        # long horizons: solves the first-stage kernel handed to the full kernel
         return int(v[0]), int(v[1]), int(v[2])
 
     def qp_failures(self):
