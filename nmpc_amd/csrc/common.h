@@ -59,8 +59,12 @@ constexpr int PK_REC1 = 20480;    // [64][4] {c2*b0[k], c2*b2[k], split-fp16 pac
 constexpr int PK_REC2 = 20736;    // [64][4] W0[k][0..3] (zero padded)
 constexpr int PK_LIN = 20992;     // [4][4]  W_lin[c][j] (zero padded)
 constexpr int PK_J0 = 21008;      // [4][4]  Jacobian of the nonlinear branch at the origin, W4 D2 W2 D1 W0 (fp64-evaluated)
-constexpr int PACK_FLOATS = 21024;
-constexpr int PK_TAIL = PACK_FLOATS - PK_REC1;   // REC1 + REC2 + LIN + J0, contiguous
+constexpr int PK_REC3 = 21024;    // [64][4] W0[k][4..7] (zero padded): nets with more than four inputs
+constexpr int PK_LIN2 = 21280;    // [4][4]  W_lin[c][4..7]
+constexpr int PK_J02 = 21296;     // [4][4]  origin Jacobian of the nonlinear branch, inputs 4..7
+constexpr int PACK_FLOATS = 21312;
+constexpr int PK_TAIL = PK_REC3 - PK_REC1;       // REC1 + REC2 + LIN + J0, contiguous: what nets with <= 4 inputs stage
+constexpr int PK_TAIL_EXT = PACK_FLOATS - PK_REC1;   // the same with the tables of inputs 4..7 behind them
 
 // One net in the layout of the general-width embedding kernel (embed_wide.hip); hidden width padded
 // to 16*ht (ht = 4, 8, 16), outputs padded to nout_pad (1, 4, 8), inputs to 16; all fp32, device.

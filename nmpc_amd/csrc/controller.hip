@@ -252,6 +252,92 @@ __global__ __launch_bounds__(256) void plant_model_kernel(CtrlDev d, RunPtrs rp,
     }
 }
 
+// Output-feedback step for the models plant_kernel does not cover (observer / output nets of any hidden width up to
+// 256, state dimensions up to 8; reference: NMPC_test.py:262-315, Systems.py:79-97): the same step - disc ODE, noisy
+// measurement, observer net on the shifted histories, output estimate, logs, warm-start shift - with one workgroup
+// per controller and the nets evaluated block-wide in fp64.
+template <int NX>
+__global__ __launch_bounds__(256) void plant_obs_block_kernel(CtrlDev d, RunPtrs rp, int k) {
+    __shared__ double in[MAX_HIST], outv[8], t1s[256], t2s[256];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    if (b == 0 && tid == 0)
+        for (int it = 0; it <= d.maxit; ++it) { if (it) d.nact[it] = 0; if (d.nslow) d.nslow[it] = 0; }
+    const int Nc = d.Nc, H = d.hidden, ns = d.n_sim;
+    double* up = d.uplan + (size_t)b * Nc;
+    double* xpd = d.xpred + (size_t)b * Nc * NX;
+    const double u_n = up[0];
+    const double u_den = d.ustd * u_n + d.u0;                       // NMPC_test.py:271
+    double w = d.xp[2 * b], th = d.xp[2 * b + 1];                   // every thread integrates the same two states
+    double k1w, k1t, k2w, k2t, k3w, k3t, k4w, k4t;
+    disc_deriv(d.plant, w, th, u_den, k1w, k1t); k1w *= d.dt; k1t *= d.dt;
+    disc_deriv(d.plant, w + k1w / 2, th + k1t / 2, u_den, k2w, k2t); k2w *= d.dt; k2t *= d.dt;
+    disc_deriv(d.plant, w + k2w / 2, th + k2t / 2, u_den, k3w, k3t); k3w *= d.dt; k3t *= d.dt;
+    disc_deriv(d.plant, w + k3w, th + k3t, u_den, k4w, k4t); k4w *= d.dt; k4t *= d.dt;
+    w += (k1w + 2 * k2w + 2 * k3w + k4w) / 6;
+    th += (k1t + 2 * k2t + 2 * k3t + k4t) / 6;
+    const double y = th + (rp.noise ? rp.noise[(size_t)k * rp.noise_ld + b] : 0.0);
+    const double yn = (y - d.y0) / d.ystd;                          // NMPC_test.py:280
+    double* uh = d.uhist + (size_t)b * d.na;
+    double* yh = d.yhist + (size_t)b * d.nyh;
+    double hv = 0.0;                                                // histories, oldest first (NMPC_test.py:283-289)
+    if (tid < d.na) hv = tid + 1 < d.na ? uh[tid + 1] : u_n;
+    else if (tid < d.na + d.nyh) { const int j = tid - d.na; hv = j + 1 < d.nyh ? yh[j + 1] : yn; }
+    // everything that is shifted is read before anything is written
+    const int e = tid;
+    const bool one = e < Nc * NX;
+    const double xold = one ? xpd[e] : 0.0;
+    const double xsh = one ? xpd[e + NX < Nc * NX ? e + NX : e] : 0.0;
+    const double upv = e < Nc ? up[e] : 0.0;
+    const double upn = e < Nc ? up[e + 1 < Nc ? e + 1 : Nc - 1] : 0.0;
+    const double epsv = d.eps[b];
+    const int cntv = d.cnt[b];
+    __syncthreads();
+    if (tid < d.na) uh[tid] = hv;
+    else if (tid < d.na + d.nyh) yh[tid - d.na] = hv;
+    if (tid < d.na + d.nyh) in[tid] = hv;
+    __syncthreads();
+    block_mlp(d.enc, d.n_enc_in, NX, H, in, t1s, t2s, outv);
+    double zest[NX];
+#pragma unroll
+    for (int r = 0; r < NX; ++r) zest[r] = outv[r];
+    __syncthreads();
+    if (tid < NX) in[tid] = outv[tid];
+    __syncthreads();
+    block_mlp(d.hplain, NX, 1, H, in, t1s, t2s, outv);
+    const double yest = outv[0];
+    if (tid == 0) {
+        d.xp[2 * b] = w; d.xp[2 * b + 1] = th;
+        d.ymeas[b] = yn;
+        if (rp.y_log) rp.y_log[(size_t)b * (ns + 1) + k + 1] = y;
+        if (rp.y_est_log) rp.y_est_log[(size_t)b * (ns + 1) + k + 1] = d.ystd * yest + d.y0;
+        if (rp.u_log) rp.u_log[(size_t)b * ns + k] = u_den;
+        if (rp.e_log) rp.e_log[(size_t)b * ns + k] = epsv;
+        if (rp.lpv_counter) rp.lpv_counter[(size_t)b * ns + k] = cntv;
+        if (rp.qp_status_log) rp.qp_status_log[(size_t)b * ns + k] = (signed char)d.qp_worst[b];
+        d.qp_worst[b] = 0;
+    }
+    if (tid < NX) {
+        double v = 0.0;
+#pragma unroll
+        for (int r = 0; r < NX; ++r) if (r == tid) v = zest[r];
+        if (rp.x_log) rp.x_log[((size_t)b * (ns + 1) + k + 1) * NX + tid] = v;
+        d.x0n[(size_t)b * NX + tid] = v;
+    }
+    if (e < Nc) {
+        if (rp.plan_log) rp.plan_log[((size_t)b * ns + k) * Nc + e] = upv;
+        up[e] = upn;
+        d.us32[(size_t)b * Nc + e] = (float)upn;
+    }
+    if (one) {
+        xpd[e] = xsh;
+        d.xc32[(size_t)b * Nc * NX + e] = (float)xsh;
+        double sv = xold;                 // x_k of the next first pass: x_0 = new estimate, x_k = shifted prediction k-1
+#pragma unroll
+        for (int r = 0; r < NX; ++r) if (r == e) sv = zest[r];
+        d.xs32[(size_t)b * Nc * NX + e] = (float)sv;
+    }
+}
+
 // State-feedback step (NMPC.py:484-495, 628-640): plant RK4, the measured state (plus noise
 // [n_sim, batch, NX]) becomes x0, logs, warm-start shift.  One thread per controller; the disc
 // plant has two states, so NX = 2.
@@ -475,10 +561,13 @@ extern "C" int nmpc_ctrl_create(nmpc_ctrl** out, const nmpc_model* m, const nmpc
     const int mode = cfg->mode;
     NMPC_REQUIRE(mode >= 0 && mode <= 2, "nmpc_ctrl_create: mode %d unknown (0 output feedback, 1 state feedback, 2 model as plant)", mode);
     NMPC_REQUIRE(mode != 0 || (m->d.enc && m->d.hplain && m->d.n_enc_in <= MAX_HIST), "nmpc_ctrl_create: model has no observer net");
-    NMPC_REQUIRE(mode != 0 || m->d.nx <= 4, "nmpc_ctrl_create: the observer loop supports nx = 2..4 (model has nx = %d)", m->d.nx);
+    NMPC_REQUIRE(mode != 0 || (m->d.nx >= 2 && m->d.nx <= 8), "nmpc_ctrl_create: the observer loop supports nx = 2..8 (model has nx = %d)", m->d.nx);
     NMPC_REQUIRE(mode != 1 || m->d.nx == 2, "nmpc_ctrl_create: state feedback drives the two-state disc plant (nx = 2)");
     NMPC_REQUIRE(mode != 2 || (m->d.fplain && m->d.hplain), "nmpc_ctrl_create: the model-as-plant loop needs nets with two hidden layers, nu = ny = 1");
-    NMPC_REQUIRE(cfg->Nc * m->d.nx <= (mode == 2 ? 256 : 128), "nmpc_ctrl_create: Nc*nx=%d exceeds %d", cfg->Nc * m->d.nx, mode == 2 ? 256 : 128);
+    {   // the one-wavefront plant step (hidden 64, nx <= 4) shifts 128 predicted-state entries, the block-wide ones 256
+        const int lim = (mode == 0 && m->d.hidden == HID && m->d.nx <= 4) ? 128 : 256;
+        NMPC_REQUIRE(cfg->Nc * m->d.nx <= lim, "nmpc_ctrl_create: Nc*nx=%d exceeds %d", cfg->Nc * m->d.nx, lim);
+    }
     NMPC_REQUIRE(cfg->batch >= 1 && cfg->max_iterations >= 1 && cfg->max_iterations <= 64 && cfg->n_sim >= 1,
                  "nmpc_ctrl_create: bad batch/max_iterations/n_sim");
     NMPC_REQUIRE(cfg->n_nodes >= 1 && cfg->n_nodes <= NMPC_MAX_NODES, "nmpc_ctrl_create: bad node count");
@@ -705,6 +794,14 @@ extern "C" int nmpc_ctrl_run(nmpc_ctrl* c, int k0, int nsteps, const double* Xs,
                 }
             }
             else if (d.c.mode == 1) hipLaunchKernelGGL((plant_state_kernel<2>), dim3((d.B + 127) / 128), dim3(128), 0, s, d, rp, k);
+            else if (d.hidden != HID || d.nx > 4) {
+                switch (d.nx) {
+#define NMPC_PO_CASE(NX_) case NX_: hipLaunchKernelGGL((plant_obs_block_kernel<NX_>), dim3(d.B), dim3(256), 0, s, d, rp, k); break;
+                    NMPC_PO_CASE(2) NMPC_PO_CASE(3) NMPC_PO_CASE(4) NMPC_PO_CASE(5) NMPC_PO_CASE(6) NMPC_PO_CASE(7) NMPC_PO_CASE(8)
+#undef NMPC_PO_CASE
+                    default: set_error("nmpc_ctrl_run: nx=%d unsupported", d.nx); return 1;
+                }
+            }
             else if (d.nx == 2) hipLaunchKernelGGL((plant_kernel<2>), dim3(grid), dim3(threads), 0, s, d, rp, k);
             else if (d.nx == 3) hipLaunchKernelGGL((plant_kernel<3>), dim3(grid), dim3(threads), 0, s, d, rp, k);
             else if (d.nx == 4) hipLaunchKernelGGL((plant_kernel<4>), dim3(grid), dim3(threads), 0, s, d, rp, k);

@@ -207,13 +207,22 @@ __global__ __launch_bounds__(EMBED_THREADS, 3) void embed_kernel(EmbedArgs a, No
     unsigned long long c0 = 0, r0 = 0;
     if (a.stamps) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }   // diagnostics only
     if (b < a.n_ftiles) {
-        if (b * EMBED_TILE >= npts) return;
-        if constexpr (MODE == 0) embed_tile<NX, NU, NX>(a.fpack, lds, a.x, a.u, a.A, a.B, b, npts, a.act, a.group, nt);
-        else embed_tile_h2<NX, NU, NX, MODE == 2>(a.fpack, lds, a.x, a.u, a.A, a.B, b, npts, a.act, a.group, nt);
+        if constexpr (NX == 4) {          // four output rows: tiles [0, n/2) compute rows 0, 1, tiles [n/2, n) rows 2, 3
+            const int half = a.n_ftiles >> 1, t = b < half ? b : b - half;
+            if (t * EMBED_TILE >= npts) return;
+            if constexpr (MODE != 0) {
+                if (b < half) embed_tile_h2<NX, NU, 2, MODE == 2, 0, 4>(a.fpack, lds, a.x, a.u, a.A, a.B, t, npts, a.act, a.group, nt);
+                else embed_tile_h2<NX, NU, 2, MODE == 2, 2, 4>(a.fpack, lds, a.x, a.u, a.A, a.B, t, npts, a.act, a.group, nt);
+            }
+        } else {
+            if (b * EMBED_TILE >= npts) return;
+            if constexpr (MODE == 0) embed_tile<NX, NU, NX>(a.fpack, lds, a.x, a.u, a.A, a.B, b, npts, a.act, a.group, nt);
+            else embed_tile_h2<NX, NU, NX, MODE == 2>(a.fpack, lds, a.x, a.u, a.A, a.B, b, npts, a.act, a.group, nt);
+        }
     } else {
         const int t = b - a.n_ftiles;
         if (t * EMBED_TILE >= npts) return;
-        if constexpr (MODE == 0) embed_tile<NX, 0, NY>(a.hpack, lds, a.xc, nullptr, a.C, nullptr, t, npts, a.act, a.group, nt);
+        if constexpr (MODE == 0) { if constexpr (NX <= 3) embed_tile<NX, 0, NY>(a.hpack, lds, a.xc, nullptr, a.C, nullptr, t, npts, a.act, a.group, nt); }
         else embed_tile_h2<NX, 0, NY, MODE == 2>(a.hpack, lds, a.xc, nullptr, a.C, nullptr, t, npts, a.act, a.group, nt);
     }
     if (a.stamps) {
@@ -304,14 +313,14 @@ int embed_launch_prepared(const ModelDev& m, EmbedArgs a, const NodeTable& nt, h
     const bool do_f = a.x && a.u && a.A && a.B, do_h = a.xc && a.C;
     NMPC_REQUIRE(do_f || do_h, "embed: nothing to compute (need x,u,A,B and/or xc,C)");
     if (a.group < 1) a.group = 1;
-    if (!m.narrow_ok || embed_mode() == 2) return embed_wide_launch(m, a, nt, stream, loop);
-    const int tiles = (a.npts + EMBED_TILE - 1) / EMBED_TILE;
     const bool h2 = embed_use_h2() && m.fpack_h2 && m.hpack_h2;
+    if (!m.narrow_ok || embed_mode() == 2 || (m.nx == 4 && !h2)) return embed_wide_launch(m, a, nt, stream, loop);
+    const int tiles = (a.npts + EMBED_TILE - 1) / EMBED_TILE;
     a.fpack = h2 ? m.fpack_h2 : m.fpack; a.hpack = h2 ? m.hpack_h2 : m.hpack;
-    a.n_ftiles = do_f ? tiles : 0;
+    a.n_ftiles = do_f ? (m.nx == 4 ? 2 * tiles : tiles) : 0;      // nx = 4: two tiles of two output rows per 16 points
     const int grid = a.n_ftiles + (do_h ? tiles : 0);
-    const int nout_max = m.nx > m.ny ? m.nx : m.ny;
-    const size_t lds_bytes = sizeof(float) * (4096 + 4096 * nout_max + PK_TAIL);
+    const int nout_tile = m.nx == 4 ? 2 : (m.nx > m.ny ? m.nx : m.ny);
+    const size_t lds_bytes = sizeof(float) * (4096 + 4096 * nout_tile + (m.nx + m.nu > 4 ? PK_TAIL_EXT : PK_TAIL));
     const int mode = !h2 ? 0 : (nt.recur ? 2 : 1);
 #define NMPC_EMBED_CASE(NX_, NU_, NY_)                                                                   \
     if (m.nx == NX_ && m.nu == NU_ && m.ny == NY_) {                                                     \
@@ -324,6 +333,7 @@ int embed_launch_prepared(const ModelDev& m, EmbedArgs a, const NodeTable& nt, h
     }
     NMPC_EMBED_CASE(2, 1, 1)
     NMPC_EMBED_CASE(3, 1, 1)
+    NMPC_EMBED_CASE(4, 1, 1)
 #undef NMPC_EMBED_CASE
     set_error("embed: no kernel instantiated for nx=%d nu=%d ny=%d", m.nx, m.nu, m.ny);
     return 1;

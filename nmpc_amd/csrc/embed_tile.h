@@ -62,33 +62,39 @@ __device__ __forceinline__ void split16(const float* v, f16x8* BH, f16x8* BL) {
 
 // RECUR: the nodes of a wave are equally spaced (nt.dlam): e = 2^-a of layer 1 is stepped from node to
 // node by one multiplication with 2^(-dlam g) instead of being evaluated (a = lam g + b0 is linear in lam).
-template <int NA, int NB, int NOUT, bool RECUR = false>
+// C0, NOUT_ALL: the tile computes output rows C0 .. C0 + NOUT - 1 of a net with NOUT_ALL rows (a net with four
+// outputs runs as two tiles of two rows each, so that three workgroups still share a CU; the forward product is
+// then evaluated twice).  Nets with more than four inputs read the tables of inputs 4..7 behind the others.
+template <int NA, int NB, int NOUT, bool RECUR = false, int C0 = 0, int NOUT_ALL = NOUT>
 __device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, float* __restrict__ lds,
                                               const float* __restrict__ pa, const float* __restrict__ pb,
                                               float* __restrict__ oa, float* __restrict__ ob, int tile, int npts,
                                               const int* __restrict__ act, int group, const NodeTable& nt) {
     constexpr int NIN = NA + NB;
+    constexpr int TAIL = NIN > 4 ? PK_TAIL_EXT : PK_TAIL;
     constexpr int L_WR = 4096, L_REC1 = 4096 + 4096 * NOUT, L_REC2 = L_REC1 + 256, L_LIN = L_REC2 + 256,
-                  L_RED = 0;
+                  L_REC3 = L_REC1 + (PK_REC3 - PK_REC1), L_LIN2 = L_REC1 + (PK_LIN2 - PK_REC1), L_RED = 0;
     static_assert(4 * EMBED_TILE * NOUT * NIN <= 4096, "reduction buffer must fit in the WF region");
+    static_assert(NIN <= 8 && C0 + NOUT <= NOUT_ALL && NOUT_ALL <= 4, "table sizes");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, hq = lane >> 4;
     {   // stage the packed net: all loads of a lane in flight before the first LDS write (a load-then-store loop
         // would pay the L2 latency once per 16 bytes)
-        constexpr int NV = (4096 + 4096 * NOUT) / 4 / EMBED_THREADS;
-        static_assert((4096 + 4096 * NOUT) / 4 % EMBED_THREADS == 0 && PK_TAIL / 4 <= EMBED_THREADS, "fill plan");
-        const f32x4* src = reinterpret_cast<const f32x4*>(pack);
+        constexpr int NVF = 4096 / 4 / EMBED_THREADS, NVR = 4096 * NOUT / 4 / EMBED_THREADS, NV = NVF + NVR;
+        static_assert(4096 / 4 % EMBED_THREADS == 0 && TAIL / 4 <= EMBED_THREADS, "fill plan");
+        const f32x4* srcf = reinterpret_cast<const f32x4*>(pack);
+        const f32x4* srcr = reinterpret_cast<const f32x4*>(pack + PK_WR + 4096 * C0) - NVF * EMBED_THREADS;
         f32x4* dst = reinterpret_cast<f32x4*>(lds);
         const f32x4* src2 = reinterpret_cast<const f32x4*>(pack + PK_REC1);
         f32x4* dst2 = reinterpret_cast<f32x4*>(lds + L_REC1);
         f32x4 stage[NV], stage2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < NV; ++k) stage[k] = src[tid + k * EMBED_THREADS];
-        if (tid < PK_TAIL / 4) stage2 = src2[tid];
+        for (int k = 0; k < NV; ++k) stage[k] = (k < NVF ? srcf : srcr)[tid + k * EMBED_THREADS];
+        if (tid < TAIL / 4) stage2 = src2[tid];
 #pragma unroll
         for (int k = 0; k < NV; ++k) dst[tid + k * EMBED_THREADS] = stage[k];
-        if (tid < PK_TAIL / 4) dst2[tid] = stage2;
+        if (tid < TAIL / 4) dst2[tid] = stage2;
     }
     __syncthreads();
     // fragment planes: [plane][T][ks][lane] of 8 halves (16 B)
@@ -96,6 +102,7 @@ __device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, fl
     const f16x8* WR = reinterpret_cast<const f16x8*>(lds + L_WR);
     const f32x4* REC1 = reinterpret_cast<const f32x4*>(lds + L_REC1);
     const f32x4* REC2 = reinterpret_cast<const f32x4*>(lds + L_REC2);
+    const f32x4* REC3 = reinterpret_cast<const f32x4*>(lds + L_REC3);      // inputs 4..7 (NIN > 4 only)
 
     const int p = tile * EMBED_TILE + n;
     const bool valid = p < npts;
@@ -114,7 +121,12 @@ __device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, fl
         const f32x4 w0 = REC2[kbase(s) + 4 * hq];
         float a = w0[0] * z[0];
 #pragma unroll
-        for (int j = 1; j < NIN; ++j) a = fmaf(w0[j], z[j], a);
+        for (int j = 1; j < (NIN < 4 ? NIN : 4); ++j) a = fmaf(w0[j], z[j], a);
+        if constexpr (NIN > 4) {
+            const f32x4 w1 = REC3[kbase(s) + 4 * hq];
+#pragma unroll
+            for (int j = 4; j < NIN; ++j) a = fmaf(w1[j - 4], z[j], a);
+        }
         g[s] = C2 * a;
     }
     float q[NOUT][16];
@@ -255,7 +267,14 @@ __device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, fl
 #pragma unroll
         for (int c = 0; c < NOUT; ++c)
 #pragma unroll
-            for (int j = 0; j < NIN; ++j) pj[c][j] = fmaf(q[c][s], w0[j], pj[c][j]);
+            for (int j = 0; j < (NIN < 4 ? NIN : 4); ++j) pj[c][j] = fmaf(q[c][s], w0[j], pj[c][j]);
+        if constexpr (NIN > 4) {
+            const f32x4 w1 = REC3[kbase(s) + 4 * hq];
+#pragma unroll
+            for (int c = 0; c < NOUT; ++c)
+#pragma unroll
+                for (int j = 4; j < NIN; ++j) pj[c][j] = fmaf(q[c][s], w1[j - 4], pj[c][j]);
+        }
     }
     const float wlast = 4.0f * wcur;               // the weight of the last run and the 4 of (1 - t1^2) / 4
     float* red = lds + L_RED;
@@ -264,7 +283,7 @@ __device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, fl
     for (int c = 0; c < NOUT; ++c)
 #pragma unroll
         for (int j = 0; j < NIN; ++j) {
-            float v = (wlast * lds[L_REC1 + 4 * c + 2]) * pj[c][j];     // weight of the last run, inverse pack scale of row c
+            float v = (wlast * lds[L_REC1 + 4 * (C0 + c) + 2]) * pj[c][j];     // weight of the last run, inverse pack scale of the row
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
             if (hq == 0) red[(wave * EMBED_TILE + n) * (NOUT * NIN) + c * NIN + j] = v;
@@ -274,6 +293,8 @@ __device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, fl
         const float sumw = nt.w_sum, wz = nt.w_zero;
         const float* j0 = lds + L_LIN + 16;
         const float* lin = lds + L_LIN;
+        const float* j02 = lds + L_LIN2 + 16;
+        const float* lin2 = lds + L_LIN2;
 #pragma unroll
         for (int c = 0; c < NOUT; ++c)
 #pragma unroll
@@ -281,9 +302,11 @@ __device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, fl
                 float v = red[(0 * EMBED_TILE + n) * (NOUT * NIN) + c * NIN + j];
 #pragma unroll
                 for (int wv = 1; wv < 4; ++wv) v += red[(wv * EMBED_TILE + n) * (NOUT * NIN) + c * NIN + j];
-                v = fmaf(sumw, lin[4 * c + j], fmaf(wz, j0[4 * c + j], v));
-                if (j < NA) oa[((size_t)row * NOUT + c) * NA + j] = v;
-                else ob[((size_t)row * NOUT + c) * NB + (j - NA)] = v;
+                const float lv = j < 4 ? lin[4 * (C0 + c) + j] : lin2[4 * (C0 + c) + (j - 4)];
+                const float jv = j < 4 ? j0[4 * (C0 + c) + j] : j02[4 * (C0 + c) + (j - 4)];
+                v = fmaf(sumw, lv, fmaf(wz, jv, v));
+                if (j < NA) oa[((size_t)row * NOUT_ALL + C0 + c) * NA + j] = v;
+                else ob[((size_t)row * NOUT_ALL + C0 + c) * NB + (j - NA)] = v;
             }
     }
 }

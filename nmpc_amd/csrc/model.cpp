@@ -42,10 +42,10 @@ static void pack_net(const float* const* p, int n_in, int n_out, std::vector<flo
     for (int k = 0; k < HID; ++k) {
         out[PK_REC1 + 4 * k + 0] = (float)(c2 * (double)b0[k]);
         out[PK_REC1 + 4 * k + 1] = (float)(c2 * (double)b2[k]);
-        for (int j = 0; j < n_in; ++j) out[PK_REC2 + 4 * k + j] = w0[k * n_in + j];
+        for (int j = 0; j < n_in; ++j) out[(j < 4 ? PK_REC2 : PK_REC3) + 4 * k + (j & 3)] = w0[k * n_in + j];
     }
     for (int c = 0; c < n_out; ++c)
-        for (int j = 0; j < n_in; ++j) out[PK_LIN + 4 * c + j] = lin_w[c * n_in + j];
+        for (int j = 0; j < n_in; ++j) out[(j < 4 ? PK_LIN : PK_LIN2) + 4 * c + (j & 3)] = lin_w[c * n_in + j];
     // nonlinear-branch Jacobian at the origin: W4 diag(1 - t2^2) W2 diag(1 - t1^2) W0
     std::vector<double> t1(HID), d2(HID), v(HID);
     for (int k = 0; k < HID; ++k) t1[k] = std::tanh((double)b0[k]);
@@ -64,7 +64,7 @@ static void pack_net(const float* const* p, int n_in, int n_out, std::vector<flo
         for (int j = 0; j < n_in; ++j) {
             double a = 0.0;
             for (int k = 0; k < HID; ++k) a += v[k] * (double)w0[k * n_in + j];
-            out[PK_J0 + 4 * c + j] = (float)a;
+            out[(j < 4 ? PK_J0 : PK_J02) + 4 * c + (j & 3)] = (float)a;
         }
     }
 }
@@ -339,7 +339,9 @@ static int model_fill(nmpc_model* m, int nx, int nu, int ny, int hidden, int Lf,
     }
     // the 64-wide kernels (embed.hip) are instantiated for these sizes; everything else runs on the
     // general-width kernel (embed_wide.hip)
-    const bool narrow = hidden == HID && nu == 1 && ny == 1 && (nx == 2 || nx == 3) && Lf == 2 && Lh == 2;
+    // (nx = 4: split-fp16 kernel only, each f tile as two tiles of two output rows; nets that do not suit the
+    // split-fp16 format stay on the general-width kernel)
+    const bool narrow = hidden == HID && nu == 1 && ny == 1 && (nx == 2 || nx == 3 || nx == 4) && Lf == 2 && Lh == 2;
     m->d.f_layers = Lf; m->d.h_layers = Lh;
     m->d.nx = nx; m->d.nu = nu; m->d.ny = ny; m->d.hidden = hidden; m->d.n_enc_in = enc ? n_enc_in : 0;
     NMPC_HIP_CHECK(hipGetDevice(&m->device));
@@ -389,7 +391,7 @@ static int model_fill(nmpc_model* m, int nx, int nu, int ny, int hidden, int Lf,
     }
     eval_net_at_zero(fn, Lf, nx, hidden, m->d.f0);
     eval_net_at_zero(hn, Lh, ny, hidden, m->d.h0);
-    // plain-layout nets for the closed loop's observer / output step (one hidden unit per lane)
+    // plain-layout nets for the closed loop's observer / output step (one hidden unit per lane or per thread)
     const bool loop_ok = hidden == HID && nu == 1 && ny == 1 && nx >= 2 && nx <= 4 && Lf == 2 && Lh == 2;
     auto upload_plain = [&](const float* const* p, int n_in, int n_out, float** dst) -> int {
         const int sz[8] = {n_out * n_in, n_out, hidden * n_in, hidden, hidden * hidden, hidden, n_out * hidden, n_out};
@@ -401,12 +403,14 @@ static int model_fill(nmpc_model* m, int nx, int nu, int ny, int hidden, int Lf,
         NMPC_HIP_CHECK(hipMemcpy(*dst, e.data(), e.size() * sizeof(float), hipMemcpyHostToDevice));
         return 0;
     };
-    NMPC_REQUIRE(!enc || loop_ok, "nmpc_model_create: an observer net needs hidden = 64, two hidden layers, nu = ny = 1, nx = 2..4");
+    (void)loop_ok;
+    NMPC_REQUIRE(!enc || (Lf == 2 && Lh == 2 && nu == 1 && ny == 1 && nx >= 2),
+                 "nmpc_model_create: an observer net needs f and h nets with two hidden layers, nu = ny = 1, nx = 2..8");
     if (Lf == 2 && Lh == 2 && nu == 1 && ny == 1) {      // closed loops: output estimate; the model as its own plant
         if (upload_plain(hn, nx, ny, &m->d.hplain)) return 1;
         if (upload_plain(fn, nx + nu, nx, &m->d.fplain)) return 1;
     }
-    if (loop_ok && enc && upload_plain(enc, n_enc_in, nx, &m->d.enc)) return 1;
+    if (enc && upload_plain(enc, n_enc_in, nx, &m->d.enc)) return 1;
     if (!narrow) {           // no 64-wide packs: the general-width kernel serves the embedding
         return 0;
     }

@@ -101,9 +101,8 @@ class Controller:
         state bounds, y0, ystd [nx] state normalisation, hard=bool, as_written=bool) for the state-feedback
         controllers (as_written: input targets and linear cost term as NMPC.py:580,591 have them)."""
         model_plant = isinstance(system, ModelPlant)
-        if encoder.nx not in ((2, 3, 4, 5, 6, 7, 8) if model_plant else (2, 3, 4)):
-            raise _lib.NmpcError("closed-loop controllers support nx = 2..4, with the model as plant 2..8 (model has nx = %d)"
-                                 % encoder.nx)
+        if encoder.nx not in (2, 3, 4, 5, 6, 7, 8):
+            raise _lib.NmpcError("closed-loop controllers support nx = 2..8 (model has nx = %d)" % encoder.nx)
         cfg = _lib.CtrlConfig()
         cfg.batch, cfg.Nc, cfg.max_iterations, cfg.n_sim = int(batch), int(Nc), int(max_iterations), int(Nsim)
         cfg.tol, cfg.rho = float(tol), float(rho)

@@ -98,20 +98,33 @@ def padded_disc_model(omodel, seed=5, extra=1):
 
 
 def narrowed_disc_model(omodel, hidden, alpha=0.5):
-    """The trained disc model with `hidden` < 64 units per layer (the reference trains 32-wide encoders as well:
-    UnbalancedDisc.ipynb, n_nodes_per_layer = 32): every net keeps its first `hidden` units with the output weights
-    scaled by alpha, and its linear part is re-fitted so that value and Jacobian at the origin are those of the
-    trained net - the closed loop then behaves like the trained one near the origin while the nonlinear branch
-    carries real numbers through every kernel."""
+    """The trained disc model with `hidden` != 64 units per layer (the reference trains 32-wide encoders as well:
+    UnbalancedDisc.ipynb, n_nodes_per_layer = 32).  hidden < 64: every net keeps its first `hidden` units with the
+    output weights scaled by alpha.  hidden > 64: every net gains units with small random weights.  Either way the
+    linear part is re-fitted so that value and Jacobian at the origin are those of the given net - the closed loop
+    then behaves like the trained one near the origin while the nonlinear branch carries real numbers through every
+    kernel.  Works on the padded models of padded_disc_model too."""
     import numpy as np
     from oracle.model import Model, ResNet
     f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    rng = np.random.default_rng(hidden)
 
-    def narrow(net):
-        k = np.arange(hidden)
-        br = ResNet(np.zeros_like(net.lin_w), np.zeros_like(net.lin_b), f32(net.w0[k]), f32(net.b0[k]), f32(net.w2[np.ix_(k, k)]),
-                    f32(net.b2[k]), f32(alpha * net.w4[:, k]), np.zeros_like(net.b4))
+    def resize(net):
+        H0 = net.hidden
+        if hidden <= H0:
+            k = np.arange(hidden)
+            w0, b0, w2, b2, w4 = net.w0[k], net.b0[k], net.w2[np.ix_(k, k)], net.b2[k], alpha * net.w4[:, k]
+        else:
+            e = hidden - H0
+            w0 = np.vstack([net.w0, 0.3 * rng.standard_normal((e, net.n_in))])
+            b0 = np.concatenate([net.b0, 0.1 * rng.standard_normal(e)])
+            w2 = np.zeros((hidden, hidden)); w2[:H0, :H0] = net.w2
+            w2[H0:, :] = rng.standard_normal((e, hidden)) / np.sqrt(hidden); w2[:H0, H0:] = 0.05 * rng.standard_normal((H0, e))
+            b2 = np.concatenate([net.b2, 0.1 * rng.standard_normal(e)])
+            w4 = np.hstack([net.w4, 0.05 * rng.standard_normal((net.n_out, e))])
+        br = ResNet(np.zeros_like(net.lin_w), np.zeros_like(net.lin_b), f32(w0), f32(b0), f32(w2), f32(b2), f32(w4),
+                    np.zeros_like(net.b4))
         z0 = np.zeros(net.n_in)
         return ResNet(f32(net.jac(z0) - br.jac(z0)), f32(net(z0) - br(z0)), br.w0, br.b0, br.w2, br.b2, br.w4, br.b4)
-    return Model(narrow(omodel.fn), narrow(omodel.hn), narrow(omodel.enc), omodel.u0, omodel.ustd, omodel.y0, omodel.ystd,
+    return Model(resize(omodel.fn), resize(omodel.hn), resize(omodel.enc), omodel.u0, omodel.ustd, omodel.y0, omodel.ystd,
                  omodel.na, omodel.nb)

@@ -428,3 +428,30 @@ def test_closed_loop_narrow_encoder(omodel, H):
     check_parity(orc, out[:12], ctrl, Nsim)
     y = out[8].cpu().numpy()
     assert np.median(np.abs(y[:, 10:Nsim + 1:5] - refs[:, 9:Nsim:5])) < 0.2
+
+
+@pytest.mark.parametrize("nx,H", [(2, 128), (5, 64), (3, 96), (8, 64), (4, 256)])
+def test_closed_loop_other_observer_shapes(omodel, nx, H):
+    """Observer closed loops beyond the disc model's shape (hidden 64, nx <= 4): wider nets (the panel embedding kernel
+    and the block-wide observer / output step) and more states (nx = 5, 8: fused condense + QP for nx > 4), with the
+    disc plant and the observer in the loop.  The disc model padded with weakly coupled extra states and / or widened
+    with extra units; 5 controllers, noisy measurement, up to 4 LPV passes, against the oracle."""
+    import nmpc_amd
+    om = omodel if nx == 2 else padded_disc_model(omodel, extra=nx - 2)
+    if H != 64:
+        om = narrowed_disc_model(om, H)
+    params = {k: [np.asarray(a, np.float32) for a in n.params()] for k, n in (("fn", om.fn), ("hn", om.hn), ("enc", om.enc))}
+    encw = nmpc_amd.Encoder(params, norm=nmpc_amd.Norm(om.u0, om.ustd, om.y0, om.ystd), na=om.na, nb=om.nb, device="cuda:0")
+    assert encw.hidden == H and encw.nx == nx
+    Nsim, B, Nc = 30, 5, 10
+    Qn = np.diag([1000.0, 10.0, 1.0, 0.5, 0.5, 0.2, 0.2, 0.1][:nx])
+    refs = np.stack([random_level_reference(Nsim + Nc, [10, 15], [-1, 1], np.random.default_rng(700 + b)) for b in range(B)])
+    noise = 0.014 * np.random.default_rng(10).standard_normal((Nsim, B))
+    orc = [output_nmpc_linear(om, -4, 4, [-1.2], [1.2], np.zeros(nx), Qn, 1.0, 0.1, 20, refs[b], Nc=Nc, Nsim=Nsim, max_iterations=4,
+                              noise=noise[:, b]) for b in range(B)]
+    plant = nmpc_amd.OutputUnbalancedDisc(dt=0.1, sigma_n=[0.014])
+    out, ctrl = nmpc_amd.output_NMPC_linear(plant, encw, -4, 4, [-1.2], [1.2], np.zeros(nx), Qn, 1.0, 0.1, 0.05, 20, refs, Nc=Nc,
+                                            Nsim=Nsim, max_iterations=4, noise=noise, return_controller=True)
+    check_parity(orc, out, ctrl, Nsim, nx=nx, target_tol=5e-5, min_same=0.97)
+    y = out[8].cpu().numpy()
+    assert np.median(np.abs(y[:, 10:Nsim + 1:5] - refs[:, 9:Nsim:5])) < 0.5      # (a modified model: it tracks loosely)
