@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnmpc_amd.so")
+# NMPC_AMD_LIB names another build of the library (A/B measurements of kernel variants); default: the in-tree one
+LIB_PATH = os.environ.get("NMPC_AMD_LIB") or os.path.join(_HERE, "libnmpc_amd.so")
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
 c_double_p = ctypes.POINTER(ctypes.c_double)
