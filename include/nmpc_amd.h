@@ -116,6 +116,10 @@ int nmpc_mpc_qp(int nb, int Nc, int nx, const double* list_A, const double* list
                 double* xpred, int* status, void* stream);
 
 /* ---- closed loop (reference: NMPC_test.py:22-320 output_NMPC_linear; plant Systems.py:79-97) -----
+ * Horizons: Nc <= 15 one wavefront per controller with everything in registers, 16..23 one wavefront with the
+ * tables in LDS, from 24 on one workgroup per controller; the longest horizon whose tables fit a CU's LDS is 60 at
+ * nx = 2, 55 at nx = 3, 52 at nx = 4, 44..39 at nx = 5..8 (output feedback), 42 with state feedback; longer ones are
+ * refused by nmpc_ctrl_create / nmpc_mpc_qp.
  * `batch` independent controllers of the same model advance together; per step and controller:
  * up to max_iterations passes of {LPV embedding at the predicted trajectory, condensing, QP,
  * prediction update} until ||u - u_old||_2 < tol, then plant RK4 step, measurement, observer,

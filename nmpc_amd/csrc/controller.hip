@@ -433,7 +433,9 @@ static int mpc_geom(int Nc, int nx, int mode, int slack, MpcGeom& g) {
     const int n = mpc_nvar(Nc, slack), mt = mpc_nrows(Nc, nx, mode);
     NMPC_REQUIRE(mt <= 4 * 64, "horizon Nc=%d gives %d constraint rows (at most 256)", Nc, mt);
     const size_t per = sizeof(double) * (size_t)mpc_lds_doubles(Nc, nx, n, mt);
-    NMPC_REQUIRE(per * (64 / g.GS) <= 160 * 1024, "horizon Nc=%d needs %zu bytes of LDS per controller: too large", Nc, per);
+    // (horizons the workgroup-per-controller kernels take never run on the one-wavefront kernel this sizes)
+    NMPC_REQUIRE(mpc_wide_applies(Nc, nx, mode, slack) || per * (64 / g.GS) <= 160 * 1024,
+                 "horizon Nc=%d needs %zu bytes of LDS per controller: too large", Nc, per);
     const int per_wave = 64 / g.GS;
     int waves = (int)((48 * 1024) / (per * per_wave));
     waves = waves < 1 ? 1 : (waves > 4 ? 4 : waves);

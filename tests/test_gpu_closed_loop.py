@@ -81,12 +81,15 @@ def check_parity(orc, out, ctrl, Nsim, traj_tol=1e-4, min_same=0.99, nx=2, targe
     assert np.abs(Xs.cpu().numpy() - st("Xs")).max() < target_tol and np.abs(Us.cpu().numpy() - st("Us")).max() < target_tol
 
 
-@pytest.mark.parametrize("Nc,nb", [(10, 64), (7, 9), (15, 9), (16, 9), (20, 9), (50, 10)])
+@pytest.mark.parametrize("Nc,nb", [(10, 64), (7, 9), (15, 9), (16, 9), (20, 9), (50, 10), (23, 6), (24, 6), (32, 6), (33, 6),
+                                   (51, 5), (60, 5)])
 def test_single_pass_plan_same_inputs(enc, omodel, Nc, nb):
     """One LPV pass from identical inputs: embedding at the scheduling points, then the condensed QP;
     the planned control sequence must match the fp64 oracle within 1e-5 relative.  Nc = 50 is the
     long-horizon configuration (51 variables, 202 constraint rows); 15 / 16 straddle the switch from the
-    register-resident to the LDS-resident factorisation, 20 uses two constraint rows per lane."""
+    register-resident to the LDS-resident factorisation, 20 uses two constraint rows per lane; 23 / 24 the switch to
+    the workgroup-per-controller kernels, 32 / 33 and 50 / 51 their instantiations, 60 is the longest horizon whose
+    tables fit a CU's LDS at nx = 2 (61 variables, 242 rows)."""
     import nmpc_amd
     from oracle import mpcutil as omu
     from oracle.nmpc import mpc_qp as omq
@@ -222,11 +225,13 @@ def test_tail_kernel_does_not_change_results(enc, monkeypatch):
             assert torch.equal(outs[0][i], o[i]), i
 
 
-def test_closed_loop_long_horizon(enc, omodel):
+@pytest.mark.parametrize("Nc", [50, 24, 60])
+def test_closed_loop_long_horizon(enc, omodel, Nc):
     """Nc = 50 (the long-horizon configuration: 51 QP variables, 202 rows), bounds u in [-3, 3],
-    y in [-1, 1] (NMPC_output.py:226-227), 3 controllers x 15 steps against the oracle."""
+    y in [-1, 1] (NMPC_output.py:226-227), 3 controllers x 15 steps against the oracle; also the shortest and the
+    longest horizon of the two-stage workgroup-per-controller solve (24, 60)."""
     import nmpc_amd
-    Nsim, B, Nc = 15, 3, 50
+    Nsim, B = 15, 3
     refs = np.stack([random_level_reference(Nsim + Nc, [10, 15], [-1, 1], np.random.default_rng(300 + b)) for b in range(B)])
     orc = [output_nmpc_linear(omodel, -3, 3, [-1.0], [1.0], np.zeros(2), Q, 1.0, 0.1, 20, refs[b], Nc=Nc, Nsim=Nsim,
                               max_iterations=4) for b in range(B)]

@@ -84,3 +84,16 @@ def test_controller_argument_errors(enc):
     c = mk(lam, w)
     with pytest.raises(nmpc_amd.NmpcError):
         c.run(0, 1)                                                  # no targets yet
+
+
+def test_horizons_beyond_the_lds_are_refused(enc):
+    """The longest horizons: 60 at nx = 2 is the last whose condensing + QP tables fit a CU's LDS (tested against the
+    oracle in test_gpu_closed_loop.py); 61..63 are refused with a message that says so, 64 (no lane left for the slack
+    variable) by the range check - nothing is launched."""
+    import nmpc_amd
+    plant = nmpc_amd.OutputUnbalancedDisc(dt=0.1, sigma_n=[0.0])
+    lam, w = nmpc_amd.quad_nodes("simpson", 20)
+    nmpc_amd.Controller(enc, plant, 2, 60, 3, 2, Q, 1.0, -2.0, 2.0, -2.0, 2.0, lam, w)
+    for Nc, word in ((61, "LDS"), (63, "LDS"), (64, "unsupported")):
+        with pytest.raises(nmpc_amd.NmpcError, match=word):
+            nmpc_amd.Controller(enc, plant, 2, Nc, 3, 2, Q, 1.0, -2.0, 2.0, -2.0, 2.0, lam, w)
