@@ -55,16 +55,21 @@ constexpr int HID = 64;             // hidden width handled by the MFMA embeddin
 // Packed-net layout (float offsets), see pack_net in model.cpp.
 constexpr int PK_WF = 0;          // [4][4][64][4]    forward A-fragments of c2*W2
 constexpr int PK_WR = 4096;       // [4][4][4][64][4] reverse A-fragments of (4 W4[c]) .* W2^T, c = 0..3
-constexpr int PK_REC1 = 20480;    // [64][4] {c2*b0[k], c2*b2[k], split-fp16 pack: inverse scale of reverse matrix k (k < 4), 0}
+constexpr int PK_REC1 = 20480;    // [64][4] {c2*b0[k], c2*b2[k], split-fp16 pack: inverse scale of reverse matrix k (k < 8), 0}
 constexpr int PK_REC2 = 20736;    // [64][4] W0[k][0..3] (zero padded)
 constexpr int PK_LIN = 20992;     // [4][4]  W_lin[c][j] (zero padded)
 constexpr int PK_J0 = 21008;      // [4][4]  Jacobian of the nonlinear branch at the origin, W4 D2 W2 D1 W0 (fp64-evaluated)
 constexpr int PK_REC3 = 21024;    // [64][4] W0[k][4..7] (zero padded): nets with more than four inputs
 constexpr int PK_LIN2 = 21280;    // [4][4]  W_lin[c][4..7]
 constexpr int PK_J02 = 21296;     // [4][4]  origin Jacobian of the nonlinear branch, inputs 4..7
-constexpr int PACK_FLOATS = 21312;
+constexpr int PK_REC4 = 21312;    // [64][4] W0[k][8..11] (zero padded): nets with more than eight inputs
+constexpr int PK_LINX = 21568;    // [8][12] W_lin[c][j]: nets with more than four outputs or eight inputs read these ...
+constexpr int PK_J0X = 21664;     // [8][12] ... and this origin Jacobian (from global memory, once per tile)
+constexpr int PK_WR2 = 21760;     // [4][4][4][64][4] reverse A-fragments of output rows c = 4..7 (split-fp16 pack only)
+constexpr int PACK_FLOATS = PK_WR2 + 4 * 4096;
 constexpr int PK_TAIL = PK_REC3 - PK_REC1;       // REC1 + REC2 + LIN + J0, contiguous: what nets with <= 4 inputs stage
-constexpr int PK_TAIL_EXT = PACK_FLOATS - PK_REC1;   // the same with the tables of inputs 4..7 behind them
+constexpr int PK_TAIL_EXT = PK_REC4 - PK_REC1;   // the same with the tables of inputs 4..7 behind them
+constexpr int PK_TAIL_EXT2 = PK_LINX - PK_REC1;  // and with W0's columns 8..11 behind those
 
 // One net in the layout of the general-width embedding kernel (embed_wide.hip); hidden width padded
 // to 16*ht (ht = 4, 8, 16), outputs padded to nout_pad (1, 4, 8), inputs to 16; all fp32, device.

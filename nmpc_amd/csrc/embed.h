@@ -51,6 +51,12 @@ int embed_prepare_nodes(const ModelDev& m, const NodeTable& nodes, NodeTable& pr
 int embed_launch_prepared(const ModelDev& m, EmbedArgs a, const NodeTable& prepared, hipStream_t stream, bool loop = false);
 // true unless NMPC_EMBED selects another kernel than the split-fp16 one for the 64-wide nets
 bool embed_split16_selected();
+// split-fp16 kernels of the nets with five to eight states (embed_nx5.hip ..): ny = 1 or 2, mode 1 plain, 2 with the
+// node recurrence; loop launches exist for ny = 1
+int embed_dispatch_nx5(int ny, const EmbedArgs& a, const NodeTable& nt, int grid, size_t lds_bytes, int mode, bool loop, hipStream_t s);
+int embed_dispatch_nx6(int ny, const EmbedArgs& a, const NodeTable& nt, int grid, size_t lds_bytes, int mode, bool loop, hipStream_t s);
+int embed_dispatch_nx7(int ny, const EmbedArgs& a, const NodeTable& nt, int grid, size_t lds_bytes, int mode, bool loop, hipStream_t s);
+int embed_dispatch_nx8(int ny, const EmbedArgs& a, const NodeTable& nt, int grid, size_t lds_bytes, int mode, bool loop, hipStream_t s);
 // general-width kernel (embed_wide.hip); nt must already have its lambda = 0 nodes folded into w_zero
 int embed_wide_launch(const ModelDev& m, const EmbedArgs& a, const NodeTable& nt, hipStream_t stream, bool loop);
 

@@ -1,0 +1,233 @@
+// Device side of the 64-wide embedding kernels and their launch template, shared by embed.hip (nx = 2..4) and the
+// per-nx instantiation units embed_nx5.hip .. embed_nx8.hip.
+#pragma once
+#include "../../include/nmpc_amd.h"
+#include "common.h"
+#include "embed.h"
+#include "embed_tile.h"
+
+namespace nmpc {
+
+// e*r and r = 1/(e+1) for e = 2^a, a = c2 * preactivation:  tanh = 1 - 2r,  1 - tanh^2 = 4 (e r) r
+__device__ __forceinline__ void tanh_parts(float a, float& e_r, float& r) {
+    a = __builtin_amdgcn_fmed3f(a, -60.0f, 60.0f);
+    const float e = __builtin_amdgcn_exp2f(a);
+    r = __builtin_amdgcn_rcpf(e + 1.0f);
+    e_r = e * r;
+}
+
+template <int NA, int NB, int NOUT>
+__device__ __forceinline__ void embed_tile(const float* __restrict__ pack, float* __restrict__ lds,
+                                           const float* __restrict__ pa, const float* __restrict__ pb,
+                                           float* __restrict__ oa, float* __restrict__ ob, int tile, int npts,
+                                           const int* __restrict__ act, int group, const NodeTable& nt) {
+    constexpr int NIN = NA + NB;
+    // the cross-wave reduction buffer aliases the (by then dead) forward fragments
+    constexpr int L_WR = 4096, L_REC1 = 4096 + 4096 * NOUT, L_REC2 = L_REC1 + 256, L_LIN = L_REC2 + 256,
+                  L_RED = 0;
+    static_assert(4 * EMBED_TILE * NOUT * NIN <= 4096, "reduction buffer must fit in the WF region");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, hq = lane >> 4;
+
+    {   // stage the packed net into LDS: WF + NOUT reverse blocks, then the small tables
+        const f32x4* src = reinterpret_cast<const f32x4*>(pack);
+        f32x4* dst = reinterpret_cast<f32x4*>(lds);
+        for (int i = tid; i < (4096 + 4096 * NOUT) / 4; i += EMBED_THREADS) dst[i] = src[i];
+        const f32x4* src2 = reinterpret_cast<const f32x4*>(pack + PK_REC1);
+        f32x4* dst2 = reinterpret_cast<f32x4*>(lds + L_REC1);
+        for (int i = tid; i < PK_TAIL / 4; i += EMBED_THREADS) dst2[i] = src2[i];
+    }
+    __syncthreads();
+    const f32x4* WF = reinterpret_cast<const f32x4*>(lds);
+    const f32x4* WR = reinterpret_cast<const f32x4*>(lds + L_WR);
+    const f32x4* REC1 = reinterpret_cast<const f32x4*>(lds + L_REC1);
+    const f32x4* REC2 = reinterpret_cast<const f32x4*>(lds + L_REC2);
+
+    const int p = tile * EMBED_TILE + n;
+    const bool valid = p < npts;
+    const int pc = valid ? p : npts - 1;
+    const int row = act ? act[pc / group] * group + pc % group : pc;
+    float z[NIN];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) z[j] = pa[(size_t)row * NA + j];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) z[NA + j] = pb[(size_t)row * NB + j];
+
+    constexpr float C2 = 2.8853900817779268f;   // 2 log2(e)
+    float g[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const f32x4 w0 = REC2[kbase(s) + 4 * hq];
+        float a = w0[0] * z[0];
+#pragma unroll
+        for (int j = 1; j < NIN; ++j) a = fmaf(w0[j], z[j], a);
+        g[s] = C2 * a;
+    }
+    float q[NOUT][16];
+#pragma unroll
+    for (int c = 0; c < NOUT; ++c)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) q[c][s] = 0.0f;
+
+    const int nn = nt.n;
+    const int n0 = (nn * wave) >> 2, n1 = (nn * (wave + 1)) >> 2;
+    for (int node = n0; node < n1; ++node) {
+        const float lam = nt.lam[node];
+        const float w4 = 4.0f * nt.w[node];
+        // Re-derive the LDS offsets from opaque values each node: the tables are loop invariant
+        // and would otherwise be hoisted into ~250 registers and spilled.
+        int lo = lane, ho = 4 * hq;
+        asm volatile("" : "+v"(lo), "+v"(ho));
+        float t1[16], wd1[16];
+        f32x4 acc[4];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const f32x4 r1 = REC1[kbase(s) + ho];
+            float er, r;
+            tanh_parts(fmaf(lam, g[s], r1[0]), er, r);
+            t1[s] = fmaf(-2.0f, r, 1.0f);
+            wd1[s] = (w4 * er) * r;               // w * (1 - t1^2)
+            acc[s >> 2][s & 3] = r1[1];
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            f32x4 a[4];
+#pragma unroll
+            for (int T = 0; T < 4; ++T) a[T] = WF[(T * 4 + s4) * 64 + lo];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int T = 0; T < 4; ++T)
+                    acc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[T][j], t1[4 * s4 + j], acc[T], 0, 0, 0);
+        }
+        float d2q[16];                             // (1 - t2^2) / 4
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            float er, r;
+            tanh_parts(acc[s >> 2][s & 3], er, r);
+            d2q[s] = er * r;
+        }
+#pragma unroll
+        for (int c = 0; c < NOUT; ++c) {
+            f32x4 rv[4];
+#pragma unroll
+            for (int T = 0; T < 4; ++T) rv[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                f32x4 a[4];
+#pragma unroll
+                for (int T = 0; T < 4; ++T) a[T] = WR[c * 1024 + (T * 4 + s4) * 64 + lo];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int T = 0; T < 4; ++T)
+                        rv[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[T][j], d2q[4 * s4 + j], rv[T], 0, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) q[c][s] = fmaf(rv[s >> 2][s & 3], wd1[s], q[c][s]);
+        }
+    }
+
+    // contraction with W0 (once per tile), then lane quarters -> one lane, waves -> LDS
+    float pj[NOUT][NIN];
+#pragma unroll
+    for (int c = 0; c < NOUT; ++c)
+#pragma unroll
+        for (int j = 0; j < NIN; ++j) pj[c][j] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const f32x4 w0 = REC2[kbase(s) + 4 * hq];
+#pragma unroll
+        for (int c = 0; c < NOUT; ++c)
+#pragma unroll
+            for (int j = 0; j < NIN; ++j) pj[c][j] = fmaf(q[c][s], w0[j], pj[c][j]);
+    }
+    float* red = lds + L_RED;
+    __syncthreads();          // every wave has finished reading WF
+#pragma unroll
+    for (int c = 0; c < NOUT; ++c)
+#pragma unroll
+        for (int j = 0; j < NIN; ++j) {
+            float v = pj[c][j];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (hq == 0) red[(wave * EMBED_TILE + n) * (NOUT * NIN) + c * NIN + j] = v;
+        }
+    __syncthreads();
+    if (tid < EMBED_TILE && valid) {
+        const float sumw = nt.w_sum, wz = nt.w_zero;
+        const float* j0 = lds + L_LIN + 16;
+        const float* lin = lds + L_LIN;
+#pragma unroll
+        for (int c = 0; c < NOUT; ++c)
+#pragma unroll
+            for (int j = 0; j < NIN; ++j) {
+                float v = red[(0 * EMBED_TILE + n) * (NOUT * NIN) + c * NIN + j];
+#pragma unroll
+                for (int wv = 1; wv < 4; ++wv) v += red[(wv * EMBED_TILE + n) * (NOUT * NIN) + c * NIN + j];
+                v = fmaf(sumw, lin[4 * c + j], fmaf(wz, j0[4 * c + j], v));
+                if (j < NA) oa[((size_t)row * NOUT + c) * NA + j] = v;
+                else ob[((size_t)row * NOUT + c) * NB + (j - NA)] = v;
+            }
+    }
+}
+
+// LOOP tags the launches made from the closed-loop step so that a profiler lists them apart from
+// the set-up launches (target selector, stand-alone calls); the code is identical.
+// MODE: 0 fp32 MFMA path (embed_tile), 1 split-fp16 path (embed_tile_h2), 2 the same with the node recurrence.
+template <int NX, int NU, int NY, bool LOOP, int MODE>
+__global__ __launch_bounds__(EMBED_THREADS, 3) void embed_kernel(EmbedArgs a, NodeTable nt) {
+    extern __shared__ __align__(16) float lds[];
+    int npts = a.npts;
+    if (a.count_dev) npts = min(npts, *a.count_dev * a.group);
+    const int b = blockIdx.x;
+    unsigned long long c0 = 0, r0 = 0;
+    if (a.stamps) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }   // diagnostics only
+    if (b < a.n_ftiles) {
+        if constexpr (NX >= 4) {          // tiles of two output rows: tiles [i n/P, (i+1) n/P) compute rows 2 i, 2 i + 1, P = ceil(NX / 2)
+            constexpr int NPAIR = (NX + 1) / 2;
+            const int per = a.n_ftiles / NPAIR, pi = b / per, t = b - pi * per;
+            if (t * EMBED_TILE >= npts) return;
+            if constexpr (MODE != 0) {
+                if (pi == 0) embed_tile_h2<NX, NU, 2, MODE == 2, 0, NX>(a.fpack, lds, a.x, a.u, a.A, a.B, t, npts, a.act, a.group, nt);
+                else if (pi == 1) embed_tile_h2<NX, NU, (NX >= 4 ? 2 : 1), MODE == 2, 2, NX>(a.fpack, lds, a.x, a.u, a.A, a.B, t, npts, a.act, a.group, nt);
+                else if constexpr (NPAIR >= 3) {
+                    if (pi == 2) embed_tile_h2<NX, NU, (NX >= 6 ? 2 : 1), MODE == 2, 4, NX>(a.fpack, lds, a.x, a.u, a.A, a.B, t, npts, a.act, a.group, nt);
+                    else if constexpr (NPAIR >= 4) embed_tile_h2<NX, NU, (NX >= 8 ? 2 : 1), MODE == 2, 6, NX>(a.fpack, lds, a.x, a.u, a.A, a.B, t, npts, a.act, a.group, nt);
+                }
+            }
+        } else {
+            if (b * EMBED_TILE >= npts) return;
+            if constexpr (MODE == 0) embed_tile<NX, NU, NX>(a.fpack, lds, a.x, a.u, a.A, a.B, b, npts, a.act, a.group, nt);
+            else embed_tile_h2<NX, NU, NX, MODE == 2>(a.fpack, lds, a.x, a.u, a.A, a.B, b, npts, a.act, a.group, nt);
+        }
+    } else {
+        const int t = b - a.n_ftiles;
+        if (t * EMBED_TILE >= npts) return;
+        if constexpr (MODE == 0) { if constexpr (NX <= 3) embed_tile<NX, 0, NY>(a.hpack, lds, a.xc, nullptr, a.C, nullptr, t, npts, a.act, a.group, nt); }
+        else embed_tile_h2<NX, 0, NY, MODE == 2>(a.hpack, lds, a.xc, nullptr, a.C, nullptr, t, npts, a.act, a.group, nt);
+    }
+    if (a.stamps) {
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0) {
+            unsigned long long* st = a.stamps + 2 * (size_t)(b % a.stamp_slots);
+            st[0] = c1 - c0; st[1] = r1 - r0;
+        }
+    }
+}
+
+template <int NX, int NU, int NY, bool LOOP, int MODE>
+int embed_launch_t(const EmbedArgs& a, const NodeTable& nt, int grid, size_t lds_bytes, hipStream_t stream) {
+    static std::atomic<unsigned long long> attr_set{0};
+    if (first_use_on_device(attr_set)) {
+        NMPC_HIP_CHECK(hipFuncSetAttribute((const void*)embed_kernel<NX, NU, NY, LOOP, MODE>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        mark_used_on_device(attr_set);
+    }
+    hipLaunchKernelGGL((embed_kernel<NX, NU, NY, LOOP, MODE>), dim3(grid), dim3(EMBED_THREADS), lds_bytes, stream, a, nt);
+    NMPC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace nmpc

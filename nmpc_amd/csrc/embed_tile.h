@@ -64,37 +64,44 @@ __device__ __forceinline__ void split16(const float* v, f16x8* BH, f16x8* BL) {
 // node by one multiplication with 2^(-dlam g) instead of being evaluated (a = lam g + b0 is linear in lam).
 // C0, NOUT_ALL: the tile computes output rows C0 .. C0 + NOUT - 1 of a net with NOUT_ALL rows (a net with four
 // outputs runs as two tiles of two rows each, so that three workgroups still share a CU; the forward product is
-// then evaluated twice).  Nets with more than four inputs read the tables of inputs 4..7 behind the others.
+// then evaluated twice; nets with five to eight outputs likewise as three or four tiles, rows 4..7 from the second
+// block of reverse fragments).  Nets with more than four inputs read the tables of inputs 4..7 behind the others,
+// those with more than eight a third table; the linear branch and the origin Jacobian of nets with more than four
+// outputs or eight inputs come from the pack in global memory (sixteen lanes, once per tile).
 template <int NA, int NB, int NOUT, bool RECUR = false, int C0 = 0, int NOUT_ALL = NOUT>
 __device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, float* __restrict__ lds,
                                               const float* __restrict__ pa, const float* __restrict__ pb,
                                               float* __restrict__ oa, float* __restrict__ ob, int tile, int npts,
                                               const int* __restrict__ act, int group, const NodeTable& nt) {
     constexpr int NIN = NA + NB;
-    constexpr int TAIL = NIN > 4 ? PK_TAIL_EXT : PK_TAIL;
+    constexpr int TAIL = NIN > 8 ? PK_TAIL_EXT2 : (NIN > 4 ? PK_TAIL_EXT : PK_TAIL);
     constexpr int L_WR = 4096, L_REC1 = 4096 + 4096 * NOUT, L_REC2 = L_REC1 + 256, L_LIN = L_REC2 + 256,
-                  L_REC3 = L_REC1 + (PK_REC3 - PK_REC1), L_LIN2 = L_REC1 + (PK_LIN2 - PK_REC1), L_RED = 0;
+                  L_REC3 = L_REC1 + (PK_REC3 - PK_REC1), L_LIN2 = L_REC1 + (PK_LIN2 - PK_REC1),
+                  L_REC4 = L_REC1 + (PK_REC4 - PK_REC1), L_RED = 0;
+    constexpr bool XTAB = NIN > 8 || NOUT_ALL > 4;      // linear branch / origin Jacobian from the [8][12] tables
     static_assert(4 * EMBED_TILE * NOUT * NIN <= 4096, "reduction buffer must fit in the WF region");
-    static_assert(NIN <= 8 && C0 + NOUT <= NOUT_ALL && NOUT_ALL <= 4, "table sizes");
+    static_assert(NIN <= 12 && C0 + NOUT <= NOUT_ALL && NOUT_ALL <= 8 && (C0 >= 4 || C0 + NOUT <= 4), "table sizes");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, hq = lane >> 4;
     {   // stage the packed net: all loads of a lane in flight before the first LDS write (a load-then-store loop
         // would pay the L2 latency once per 16 bytes)
         constexpr int NVF = 4096 / 4 / EMBED_THREADS, NVR = 4096 * NOUT / 4 / EMBED_THREADS, NV = NVF + NVR;
-        static_assert(4096 / 4 % EMBED_THREADS == 0 && TAIL / 4 <= EMBED_THREADS, "fill plan");
+        static_assert(4096 / 4 % EMBED_THREADS == 0 && TAIL / 4 <= 2 * EMBED_THREADS, "fill plan");
         const f32x4* srcf = reinterpret_cast<const f32x4*>(pack);
-        const f32x4* srcr = reinterpret_cast<const f32x4*>(pack + PK_WR + 4096 * C0) - NVF * EMBED_THREADS;
+        const f32x4* srcr = reinterpret_cast<const f32x4*>(pack + (C0 < 4 ? PK_WR + 4096 * C0 : PK_WR2 + 4096 * (C0 - 4))) - NVF * EMBED_THREADS;
         f32x4* dst = reinterpret_cast<f32x4*>(lds);
         const f32x4* src2 = reinterpret_cast<const f32x4*>(pack + PK_REC1);
         f32x4* dst2 = reinterpret_cast<f32x4*>(lds + L_REC1);
-        f32x4 stage[NV], stage2 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 stage[NV], stage2 = {0.f, 0.f, 0.f, 0.f}, stage3 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < NV; ++k) stage[k] = (k < NVF ? srcf : srcr)[tid + k * EMBED_THREADS];
         if (tid < TAIL / 4) stage2 = src2[tid];
+        if constexpr (TAIL / 4 > EMBED_THREADS) { if (tid + EMBED_THREADS < TAIL / 4) stage3 = src2[tid + EMBED_THREADS]; }
 #pragma unroll
         for (int k = 0; k < NV; ++k) dst[tid + k * EMBED_THREADS] = stage[k];
         if (tid < TAIL / 4) dst2[tid] = stage2;
+        if constexpr (TAIL / 4 > EMBED_THREADS) { if (tid + EMBED_THREADS < TAIL / 4) dst2[tid + EMBED_THREADS] = stage3; }
     }
     __syncthreads();
     // fragment planes: [plane][T][ks][lane] of 8 halves (16 B)
@@ -103,6 +110,7 @@ __device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, fl
     const f32x4* REC1 = reinterpret_cast<const f32x4*>(lds + L_REC1);
     const f32x4* REC2 = reinterpret_cast<const f32x4*>(lds + L_REC2);
     const f32x4* REC3 = reinterpret_cast<const f32x4*>(lds + L_REC3);      // inputs 4..7 (NIN > 4 only)
+    const f32x4* REC4 = reinterpret_cast<const f32x4*>(lds + L_REC4);      // inputs 8..11 (NIN > 8 only)
 
     const int p = tile * EMBED_TILE + n;
     const bool valid = p < npts;
@@ -125,7 +133,12 @@ __device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, fl
         if constexpr (NIN > 4) {
             const f32x4 w1 = REC3[kbase(s) + 4 * hq];
 #pragma unroll
-            for (int j = 4; j < NIN; ++j) a = fmaf(w1[j - 4], z[j], a);
+            for (int j = 4; j < (NIN < 8 ? NIN : 8); ++j) a = fmaf(w1[j - 4], z[j], a);
+        }
+        if constexpr (NIN > 8) {
+            const f32x4 w2 = REC4[kbase(s) + 4 * hq];
+#pragma unroll
+            for (int j = 8; j < NIN; ++j) a = fmaf(w2[j - 8], z[j], a);
         }
         g[s] = C2 * a;
     }
@@ -273,7 +286,14 @@ __device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, fl
 #pragma unroll
             for (int c = 0; c < NOUT; ++c)
 #pragma unroll
-                for (int j = 4; j < NIN; ++j) pj[c][j] = fmaf(q[c][s], w1[j - 4], pj[c][j]);
+                for (int j = 4; j < (NIN < 8 ? NIN : 8); ++j) pj[c][j] = fmaf(q[c][s], w1[j - 4], pj[c][j]);
+        }
+        if constexpr (NIN > 8) {
+            const f32x4 w2 = REC4[kbase(s) + 4 * hq];
+#pragma unroll
+            for (int c = 0; c < NOUT; ++c)
+#pragma unroll
+                for (int j = 8; j < NIN; ++j) pj[c][j] = fmaf(q[c][s], w2[j - 8], pj[c][j]);
         }
     }
     const float wlast = 4.0f * wcur;               // the weight of the last run and the 4 of (1 - t1^2) / 4
@@ -302,8 +322,12 @@ __device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, fl
                 float v = red[(0 * EMBED_TILE + n) * (NOUT * NIN) + c * NIN + j];
 #pragma unroll
                 for (int wv = 1; wv < 4; ++wv) v += red[(wv * EMBED_TILE + n) * (NOUT * NIN) + c * NIN + j];
-                const float lv = j < 4 ? lin[4 * (C0 + c) + j] : lin2[4 * (C0 + c) + (j - 4)];
-                const float jv = j < 4 ? j0[4 * (C0 + c) + j] : j02[4 * (C0 + c) + (j - 4)];
+                float lv, jv;
+                if constexpr (XTAB) { lv = pack[PK_LINX + 12 * (C0 + c) + j]; jv = pack[PK_J0X + 12 * (C0 + c) + j]; }
+                else {
+                    lv = j < 4 ? lin[4 * (C0 + c) + j] : lin2[4 * (C0 + c) + (j - 4)];
+                    jv = j < 4 ? j0[4 * (C0 + c) + j] : j02[4 * (C0 + c) + (j - 4)];
+                }
                 v = fmaf(sumw, lv, fmaf(wz, jv, v));
                 if (j < NA) oa[((size_t)row * NOUT_ALL + C0 + c) * NA + j] = v;
                 else ob[((size_t)row * NOUT_ALL + C0 + c) * NB + (j - NA)] = v;

@@ -36,16 +36,19 @@ static void pack_net(const float* const* p, int n_in, int n_out, std::vector<flo
                 const size_t o = ((size_t)(T * 4 + (s >> 2)) * 64 + lane) * 4 + (s & 3);
                 out[PK_WF + o] = (float)(c2 * (double)w2[(16 * T + r) * HID + k]);
                 // reverse product r1[kk] = sum_i W2[i][kk] * (4 W4[c][i]) * (d2[i]/4); reduction index i = k
-                for (int c = 0; c < n_out; ++c)
+                for (int c = 0; c < n_out && c < 4; ++c)       // (the fp32-MFMA kernel serves nets with up to three outputs)
                     out[PK_WR + 4096 * c + o] = (float)((double)w2[k * HID + 16 * T + r] * 4.0 * (double)w4[c * HID + k]);
             }
     for (int k = 0; k < HID; ++k) {
         out[PK_REC1 + 4 * k + 0] = (float)(c2 * (double)b0[k]);
         out[PK_REC1 + 4 * k + 1] = (float)(c2 * (double)b2[k]);
-        for (int j = 0; j < n_in; ++j) out[(j < 4 ? PK_REC2 : PK_REC3) + 4 * k + (j & 3)] = w0[k * n_in + j];
+        for (int j = 0; j < n_in; ++j) out[(j < 4 ? PK_REC2 : (j < 8 ? PK_REC3 : PK_REC4)) + 4 * k + (j & 3)] = w0[k * n_in + j];
     }
     for (int c = 0; c < n_out; ++c)
-        for (int j = 0; j < n_in; ++j) out[(j < 4 ? PK_LIN : PK_LIN2) + 4 * c + (j & 3)] = lin_w[c * n_in + j];
+        for (int j = 0; j < n_in; ++j) {
+            if (c < 4 && j < 8) out[(j < 4 ? PK_LIN : PK_LIN2) + 4 * c + (j & 3)] = lin_w[c * n_in + j];
+            out[PK_LINX + 12 * c + j] = lin_w[c * n_in + j];
+        }
     // nonlinear-branch Jacobian at the origin: W4 diag(1 - t2^2) W2 diag(1 - t1^2) W0
     std::vector<double> t1(HID), d2(HID), v(HID);
     for (int k = 0; k < HID; ++k) t1[k] = std::tanh((double)b0[k]);
@@ -64,7 +67,8 @@ static void pack_net(const float* const* p, int n_in, int n_out, std::vector<flo
         for (int j = 0; j < n_in; ++j) {
             double a = 0.0;
             for (int k = 0; k < HID; ++k) a += v[k] * (double)w0[k * n_in + j];
-            out[(j < 4 ? PK_J0 : PK_J02) + 4 * c + (j & 3)] = (float)a;
+            if (c < 4 && j < 8) out[(j < 4 ? PK_J0 : PK_J02) + 4 * c + (j & 3)] = (float)a;
+            out[PK_J0X + 12 * c + j] = (float)a;
         }
     }
 }
@@ -83,10 +87,12 @@ static bool pack_net_h2(const float* const* p, int n_in, int n_out, std::vector<
     const double c2 = 2.0 * 1.4426950408889634074;
     _Float16* base = reinterpret_cast<_Float16*>(out.data());
     bool ok = true;
-    double wmax[5] = {0, 0, 0, 0, 0};              // forward matrix, reverse matrices c = 0..3
+    double wmax[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // forward matrix, reverse matrices c = 0..7
+    auto rev_region = [](int c) { return (size_t)(c < 4 ? PK_WR + 4096 * c : PK_WR2 + 4096 * (c - 4)); };
     auto put = [&](size_t region_floats, int T, int ks, int lane, int j, double w) {
         if (!(std::fabs(w) < 6.0e4)) ok = false;
-        double& mx = wmax[region_floats == (size_t)PK_WF ? 0 : 1 + (region_floats - PK_WR) / 4096];
+        double& mx = wmax[region_floats == (size_t)PK_WF ? 0
+                          : (region_floats >= (size_t)PK_WR2 ? 5 + (region_floats - PK_WR2) / 4096 : 1 + (region_floats - PK_WR) / 4096)];
         mx = std::fabs(w) > mx ? std::fabs(w) : mx;
         const _Float16 h = (_Float16)(float)w;
         const _Float16 l = (_Float16)(float)(w - (double)(float)h);   // unscaled remainder (subnormals kept)
@@ -97,7 +103,7 @@ static bool pack_net_h2(const float* const* p, int n_in, int n_out, std::vector<
     // Each reverse matrix is stored times a power of two that brings its largest entry into [0.5, 1), so
     // that the unscaled fp16 remainders resolve it to 2^-24 of that entry whatever the size of W4's
     // row; the kernel multiplies the accumulated row by the inverse (REC1[4 c + 2]) once at the end.
-    double rscale[4] = {1.0, 1.0, 1.0, 1.0};
+    double rscale[8] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
     for (int c = 0; c < n_out; ++c) {
         double mx = 0.0;
         for (int k = 0; k < HID; ++k)
@@ -117,7 +123,7 @@ static bool pack_net_h2(const float* const* p, int n_in, int n_out, std::vector<
                     const int k = 16 * (2 * ks + (j >> 2)) + 4 * hq + (j & 3);
                     put(PK_WF, T, ks, lane, j, 2.0 * c2 * (double)w2[(16 * T + r) * HID + k]);
                     for (int c = 0; c < n_out; ++c)
-                        put(PK_WR + 4096 * c, T, ks, lane, j,
+                        put(rev_region(c), T, ks, lane, j,
                             rscale[c] * (double)w2[k * HID + 16 * T + r] * 4.0 * (double)w4[c * HID + k]);
                 }
     // The forward product takes r = (1 + t1) / 2 = 1 / (1 + 2^-a) as its operand instead of t1 = tanh:
@@ -341,7 +347,10 @@ static int model_fill(nmpc_model* m, int nx, int nu, int ny, int hidden, int Lf,
     // general-width kernel (embed_wide.hip)
     // (nx = 4: split-fp16 kernel only, each f tile as two tiles of two output rows; nets that do not suit the
     // split-fp16 format stay on the general-width kernel)
-    const bool narrow = hidden == HID && nu == 1 && ny == 1 && (nx == 2 || nx == 3 || nx == 4) && Lf == 2 && Lh == 2;
+    // (nx = 5..8 with one or two outputs, the shape of the reference's sin/cos encoder, sinCos.ipynb cell 6: split-fp16
+    // kernel only, f tiles of two output rows each)
+    const bool narrow = hidden == HID && nu == 1 && Lf == 2 && Lh == 2 &&
+                        ((ny == 1 && nx >= 2 && nx <= 8) || (ny == 2 && nx >= 5 && nx <= 8));
     m->d.f_layers = Lf; m->d.h_layers = Lh;
     m->d.nx = nx; m->d.nu = nu; m->d.ny = ny; m->d.hidden = hidden; m->d.n_enc_in = enc ? n_enc_in : 0;
     NMPC_HIP_CHECK(hipGetDevice(&m->device));

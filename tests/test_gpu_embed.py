@@ -221,10 +221,10 @@ def test_ablist_family_on_golden(enc, golden):
 
 @pytest.mark.parametrize("nx,nu,ny,H", [(4, 1, 1, 64), (8, 1, 3, 64), (3, 2, 2, 128), (8, 1, 1, 256), (5, 1, 2, 100)])
 def test_wide_nets(nx, nu, ny, H):
-    """Nets beyond the 64-wide kernels (deepSI encoders with nx = 4 and 8: LTI.ipynb cell 5, sinCos.ipynb
-    cell 6; the synthetic nx = 8 / H = 256 configuration) run on the general-width kernels: exact-fp32 MFMA with
-    weight fragments streamed from L2 for widths up to 64, the split-fp16 panel kernel above that.  H = 100
-    exercises the zero padding of hidden units."""
+    """Shapes beside the canonical one: nx = 4 at width 64 (the reference's LTI encoder, LTI.ipynb cell 5) on the
+    split-fp16 tile as two tiles of two output rows; three outputs or two inputs (general-width exact-fp32 MFMA kernel
+    with weight fragments streamed from L2); widths above 64 (the synthetic nx = 8 / H = 256 configuration) on the
+    split-fp16 panel kernel.  H = 100 exercises the zero padding of hidden units."""
     import nmpc_amd
     from oracle.model import Model
     om = Model.synthetic(nx, nu, ny, H, seed=3)
@@ -470,3 +470,40 @@ def test_panel_kernel_out_of_range_and_huge_bias(nx, H):
         worst = max(worst, err)
         assert err < 5e-6, err              # (2.4e-6 observed at H = 128; ordinary points: 8e-7; the bar is 1e-5)
     print("panel kernel, nx %d H %d, out-of-range points and pinned units: worst error %.2e of the matrix scale" % (nx, H, worst))
+
+
+@pytest.mark.parametrize("nx,ny,H", [(5, 1, 64), (6, 2, 64), (7, 1, 48), (8, 2, 64), (8, 1, 32)])
+def test_five_to_eight_states_on_the_split_tile(nx, ny, H):
+    """Nets with five to eight states, one input and one or two outputs (the reference's sin/cos encoder: nx = 8,
+    two outputs, sinCos.ipynb cell 6; deepSI's default width 64) run on the split-fp16 tile as three or four tiles of
+    two output rows per 16 points (rows 4..7 from the second block of reverse fragments, nine inputs through the third
+    input table, linear branch and origin Jacobian from the [8][12] tables): the bar of every other kernel against the
+    fp64 oracle - also far out of range and with a pinned unit - at ragged sizes, and the same launch twice gives
+    the same bits."""
+    import nmpc_amd
+    from oracle.model import Model
+    om = Model.synthetic(nx, 1, ny, H, seed=21)
+    om.fn.b0[3] = 45.0
+    om = Model(om.fn, om.hn, None)
+    params = {k: [np.asarray(a, np.float32) for a in n.params()] for k, n in (("fn", om.fn), ("hn", om.hn))}
+    enc = nmpc_amd.Encoder(params, device="cuda:0")
+    rng = np.random.default_rng(nx * 10 + ny)
+    lam, w = nmpc_amd.quad_nodes("simpson", 20)
+    nodes = olpv.merge_nodes(*olpv.quad_nodes("simpson", 20))
+    for P in (1, 16, 17, 200):
+        x = f32(rng.uniform(-2, 2, (P, nx))); u = f32(rng.uniform(-2, 2, (P, 1))); xc = f32(rng.uniform(-2, 2, (P, nx)))
+        if P == 200:
+            x[16:32] *= 300.0; u[16:32] *= 300.0; xc[16:32] *= 300.0; x[77] *= 2000.0; xc[78] *= 2000.0
+        A, B, C = nmpc_amd.embed(enc, torch.tensor(x), torch.tensor(u), torch.tensor(xc), lam, w)
+        assert A.shape == (P, nx, nx) and B.shape == (P, nx, 1) and C.shape == (P, ny, nx)
+        assert torch.isfinite(A).all() and torch.isfinite(B).all() and torch.isfinite(C).all()
+        Ao, Bo, Co = olpv.embed(om, x, u, *nodes, xc=xc)
+        for got, ref in ((A, Ao), (B, Bo), (C, Co)):
+            err = np.abs(got.cpu().numpy().astype(np.float64).reshape(ref.shape) - ref).max()
+            assert err / np.abs(ref).max() < TOL, (nx, ny, H, P, err / np.abs(ref).max())
+        A2, B2, C2 = nmpc_amd.embed(enc, torch.tensor(x), torch.tensor(u), torch.tensor(xc), lam, w)
+        assert torch.equal(A, A2) and torch.equal(B, B2) and torch.equal(C, C2)
+        # A and B only, C only
+        A3, B3, _ = nmpc_amd.embed(enc, torch.tensor(x), torch.tensor(u), None, lam, w)
+        _, _, C3 = nmpc_amd.embed(enc, None, None, torch.tensor(xc), lam, w)
+        assert torch.equal(A, A3) and torch.equal(B, B3) and torch.equal(C, C3)
