@@ -5,9 +5,9 @@
 
 namespace nmpc {
 
-// true when the tail kernel is instantiated for this controller set-up (canonical shapes of the reference's
-// output-feedback loop, NMPC_test.py:326-344: nx = 2, nu = ny = 1, Nc = 10, slack on every row) and the model's
-// split-fp16 packs are in use
+// true when the tail kernel is instantiated for this controller set-up (the reference's output-feedback loop,
+// NMPC_test.py:326-344, with two or three states, nu = ny = 1, horizons up to 15, slack on every row; the canonical
+// Nc = 10 at nx = 2 with the horizon as a compile-time constant) and the model's split-fp16 packs are in use
 bool mpc_tail_applies(const CtrlDev& d, const ModelDev& m, const MpcGeom& g);
 int launch_mpc_tail(const CtrlDev& d, const RunPtrs& rp, const ModelDev& m, const NodeTable& nt, int it0, int k, hipStream_t s);
 

@@ -28,7 +28,8 @@ __global__ __launch_bounds__(EMBED_THREADS, 1) void mpc_tail_kernel(CtrlDev d, R
     extern __shared__ __align__(16) float tail_lds[];
     __shared__ int more_s;
     const int count = min(d.nact[t.it0], d.B);
-    constexpr int tiles = (NC + EMBED_TILE - 1) / EMBED_TILE;
+    const int Nc = NC ? NC : d.Nc;                    // NC = 0: horizon known at run time (as the batch-wide solve kernel of that shape)
+    const int tiles = (Nc + EMBED_TILE - 1) / EMBED_TILE;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     // a small grid walks the work list: the launch is empty most of the time, and a workgroup of this kernel needs a
     // whole CU's registers, so every workgroup that is only dispatched to exit would still wait for one
@@ -43,12 +44,12 @@ __global__ __launch_bounds__(EMBED_THREADS, 1) void mpc_tail_kernel(CtrlDev d, R
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #pragma unroll 1
         for (int tile = 0; tile < tiles; ++tile) {
-            embed_tile_h2<NX, NU, NX, RECUR>(t.fpack, tail_lds, d.xs32, d.us32, d.A32, d.B32, tile, NC, slot, NC, nt);
+            embed_tile_h2<NX, NU, NX, RECUR>(t.fpack, tail_lds, d.xs32, d.us32, d.A32, d.B32, tile, Nc, slot, Nc, nt);
             __syncthreads();
         }
 #pragma unroll 1
         for (int tile = 0; tile < tiles; ++tile) {
-            embed_tile_h2<NX, 0, NY, RECUR>(t.hpack, tail_lds, d.xc32, nullptr, d.C32, nullptr, tile, NC, slot, NC, nt);
+            embed_tile_h2<NX, 0, NY, RECUR>(t.hpack, tail_lds, d.xc32, nullptr, d.C32, nullptr, tile, Nc, slot, Nc, nt);
             __syncthreads();
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -73,22 +74,24 @@ static size_t tail_lds_bytes(const CtrlDev& d, const ModelDev& m) {
     return e > q ? e : q;
 }
 
+// Output feedback with the slack variable, nu = ny = 1, two or three states (whole-net tiles), horizons of the
+// one-wavefront register solve with one constraint row per lane (Nc <= 15).
 bool mpc_tail_applies(const CtrlDev& d, const ModelDev& m, const MpcGeom& g) {
-    return m.narrow_ok && m.fpack_h2 && m.hpack_h2 && embed_split16_selected() && d.nx == 2 && m.nu == 1 && m.ny == 1 &&
-           d.Nc == 10 && d.c.mode == 0 && d.c.slack && g.GS == 64 && g.mpl <= 1;
+    return m.narrow_ok && m.fpack_h2 && m.hpack_h2 && embed_split16_selected() && (d.nx == 2 || d.nx == 3) && m.nu == 1 && m.ny == 1 &&
+           d.Nc <= 15 && d.c.mode == 0 && d.c.slack && g.GS == 64 && g.mpl <= 1;
 }
 
-template <bool RECUR>
+template <int NX, int NC, bool RECUR>
 static int tail_launch_t(const CtrlDev& d, const RunPtrs& rp, const TailArgs& t, const NodeTable& nt, int k, size_t lds,
                          hipStream_t s) {
     static std::atomic<unsigned long long> once{0};
     if (first_use_on_device(once)) {
-        NMPC_HIP_CHECK(hipFuncSetAttribute((const void*)mpc_tail_kernel<2, 1, 1, 1, 10, RECUR>,
+        NMPC_HIP_CHECK(hipFuncSetAttribute((const void*)mpc_tail_kernel<NX, 1, 1, 1, NC, RECUR>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));   // beside 16 B static
         mark_used_on_device(once);
     }
     const int grid = d.B < TAIL_GRID ? d.B : TAIL_GRID;
-    hipLaunchKernelGGL((mpc_tail_kernel<2, 1, 1, 1, 10, RECUR>), dim3(grid), dim3(EMBED_THREADS), lds, s, d, rp, t, nt, k);
+    hipLaunchKernelGGL((mpc_tail_kernel<NX, 1, 1, 1, NC, RECUR>), dim3(grid), dim3(EMBED_THREADS), lds, s, d, rp, t, nt, k);
     NMPC_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -97,7 +100,11 @@ int launch_mpc_tail(const CtrlDev& d, const RunPtrs& rp, const ModelDev& m, cons
     NMPC_REQUIRE(nt.prepared == 1 && it0 >= 1 && it0 < d.maxit, "tail launch: bad arguments");
     TailArgs t{m.fpack_h2, m.hpack_h2, it0};
     const size_t lds = tail_lds_bytes(d, m);
-    return nt.recur ? tail_launch_t<true>(d, rp, t, nt, k, lds, s) : tail_launch_t<false>(d, rp, t, nt, k, lds, s);
+    // the solve body is the instantiation the batch-wide kernel of the same shape uses (mpc_nx2.hip, mpc_nx3.hip), so the
+    // logs do not depend on where a pass ran
+    if (d.nx == 2 && d.Nc == 10) return nt.recur ? tail_launch_t<2, 10, true>(d, rp, t, nt, k, lds, s) : tail_launch_t<2, 10, false>(d, rp, t, nt, k, lds, s);
+    if (d.nx == 2) return nt.recur ? tail_launch_t<2, 0, true>(d, rp, t, nt, k, lds, s) : tail_launch_t<2, 0, false>(d, rp, t, nt, k, lds, s);
+    return nt.recur ? tail_launch_t<3, 0, true>(d, rp, t, nt, k, lds, s) : tail_launch_t<3, 0, false>(d, rp, t, nt, k, lds, s);
 }
 
 }  // namespace nmpc

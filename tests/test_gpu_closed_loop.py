@@ -203,21 +203,31 @@ def test_slices_do_not_change_results(enc, monkeypatch):
             assert torch.equal(outs[0][i], o[i]), i
 
 
-def test_tail_kernel_does_not_change_results(enc, monkeypatch):
-    """LPV passes 3 and 4 of the canonical configuration run in one per-controller launch (embedding tile + solve body
-    in a loop) instead of two batch-wide launches each; switching that off, or starting the per-controller launch one
-    pass earlier or later, must not change a single bit of the logs.  Noisy measurements and a tight stop tolerance
-    make a sizeable share of the controllers take three and four passes."""
+@pytest.mark.parametrize("nx,Nc", [(2, 10), (2, 7), (2, 15), (3, 10)])
+def test_tail_kernel_does_not_change_results(enc, omodel, monkeypatch, nx, Nc):
+    """LPV passes 3 and 4 run in one per-controller launch (embedding tile + solve body in a loop) instead of two
+    batch-wide launches each; switching that off, or starting the per-controller launch one pass earlier or later,
+    must not change a single bit of the logs.  Noisy measurements and a tight stop tolerance make a sizeable share of
+    the controllers take three and four passes.  The canonical configuration (its horizon a compile-time constant),
+    other horizons of the one-wavefront solve, and a three-state model."""
     import nmpc_amd
-    B, Nsim, Nc = 301, 25, 10
+    B, Nsim = 301 if Nc == 10 and nx == 2 else 96, 25
     refs = np.stack([random_level_reference(Nsim + Nc, [10, 15], [-1, 1], np.random.default_rng(150 + b)) for b in range(B)])
     noise = 0.014 * np.random.default_rng(12).standard_normal((Nsim, B))
     plant = nmpc_amd.OutputUnbalancedDisc(dt=0.1, sigma_n=[0.014])
+    Qn = Q
+    if nx == 3:
+        om3 = padded_disc_model(omodel, extra=1)
+        params = {k: [np.asarray(a, np.float32) for a in n.params()] for k, n in (("fn", om3.fn), ("hn", om3.hn), ("enc", om3.enc))}
+        enc = nmpc_amd.Encoder(params, norm=nmpc_amd.Norm(om3.u0, om3.ustd, om3.y0, om3.ystd), na=om3.na, nb=om3.nb, device="cuda:0")
+        Qn = np.diag([1000.0, 10.0, 1.0])
     outs = []
     for tail in ("0", "2", "1", "3"):
         monkeypatch.setenv("NMPC_CTRL_TAIL", tail)
-        outs.append(nmpc_amd.output_NMPC_linear(plant, enc, -4, 4, [-1.2], [1.2], np.zeros(2), Q, 1.0, 0.1, 0.05, 20, refs,
-                                                Nc=Nc, Nsim=Nsim, max_iterations=4, tol=1e-3, noise=noise))
+        o, ctrl = nmpc_amd.output_NMPC_linear(plant, enc, -4, 4, [-1.2], [1.2], np.zeros(nx), Qn, 1.0, 0.1, 0.05, 20, refs,
+                                              Nc=Nc, Nsim=Nsim, max_iterations=4, tol=1e-3, noise=noise, return_controller=True)
+        assert ctrl.tail_from == int(tail)                         # the per-controller launch serves this shape
+        outs.append(o)
     cnt = outs[0][6].cpu().numpy()
     assert (cnt >= 3).mean() > 0.05 and (cnt == 4).any()          # the later passes are exercised
     for o in outs[1:]:
