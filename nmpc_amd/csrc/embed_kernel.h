@@ -177,7 +177,7 @@ __device__ __forceinline__ void embed_tile(const float* __restrict__ pack, float
 // the set-up launches (target selector, stand-alone calls); the code is identical.
 // MODE: 0 fp32 MFMA path (embed_tile), 1 split-fp16 path (embed_tile_h2), 2 the same with the node recurrence.
 template <int NX, int NU, int NY, bool LOOP, int MODE>
-__global__ __launch_bounds__(EMBED_THREADS, 3) void embed_kernel(EmbedArgs a, NodeTable nt) {
+__global__ __launch_bounds__(EMBED_THREADS, NX >= 7 ? 2 : 3) void embed_kernel(EmbedArgs a, NodeTable nt) {   // (seven and eight states: the nine-input prologue and epilogue spill hundreds of registers at three waves per SIMD)
     extern __shared__ __align__(16) float lds[];
     int npts = a.npts;
     if (a.count_dev) npts = min(npts, *a.count_dev * a.group);
