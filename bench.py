@@ -566,6 +566,10 @@ def wide_bench(args, rank, world, dev, shard):
     ach = B * Nc * flops_pt / (te * 1e-3) / 1e12
     f32_wide = os.environ.get("NMPC_EMBED_WIDE") == "f32"      # diagnostic switch: the exact-fp32 streaming kernel
     peak = FP32_MFMA_PEAK_TFLOPS if f32_wide else FP16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS
+    # HBM traffic of an embedding launch (mean over the f-net and h-net launches of the committed PMC passes); algorithmic:
+    # inputs and outputs of the points (x, u / xc in, A, B / C out, fp32) + one net's fragments and tables once
+    tr5, tr5_src = (None, None) if f32_wide else pmc_traffic("r3_cfg5_pmc_embed.json")
+    alg5 = 0.5 * (B * Nc * 4.0 * (nx + nu + nx + nx * nx + nx * nu + ny * nx)) + 2.0 * H * H * 4 + 4.0 * H * 32
     return {
         "metric": "open-loop LPV-NMPC controller-iterations/sec (cfg5: nx=8, hidden 256, N=20, %d controllers)" % int(tot_ctrl),
         "value": tot_ctrl * K / (region_max[0] * 1e-3), "unit": "controller-iterations/s", "n_gpus": world, "steps": K,
@@ -580,7 +584,9 @@ def wide_bench(args, rank, world, dev, shard):
         "n_ranks_seen": int(round(n_ranks_seen)), "ms_per_step_repeats": [m / K for m in region_max],
         "qp_status_nonzero": int(tot_fail), "gathered_rows": int(gathered["u"].shape[0]),
         "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                     "frac": ach / peak, "traffic": None, "kernel": "embed_wide_kernel" if f32_wide else "embed_panel_kernel",
+                     "frac": ach / peak, "traffic": tr5, "traffic_detail": tr5_src,
+                     "algorithmic_bytes_per_launch": alg5, "traffic_over_algorithmic": (tr5 / alg5) if tr5 else None,
+                     "kernel": "embed_wide_kernel" if f32_wide else "embed_panel_kernel",
                      "avg_launch_ms": te, "flops_per_launch": B * Nc * flops_pt,
                      "launch_note": "one embedding call = two launches (f net, h net), event-timed together",
                      "peak_note": ("exact-f32 MFMA (v_mfma_f32_16x16x4_f32) peak" if f32_wide else
