@@ -101,9 +101,10 @@ int embed_launch_prepared(const ModelDev& m, EmbedArgs a, const NodeTable& nt, h
     if (!m.narrow_ok || embed_mode() == 2 || (m.nx >= 4 && !h2)) return embed_wide_launch(m, a, nt, stream, loop);
     const int tiles = (a.npts + EMBED_TILE - 1) / EMBED_TILE;
     a.fpack = h2 ? m.fpack_h2 : m.fpack; a.hpack = h2 ? m.hpack_h2 : m.hpack;
-    a.n_ftiles = do_f ? (m.nx >= 4 ? (m.nx + 1) / 2 * tiles : tiles) : 0;     // nx >= 4: tiles of two output rows, ceil(nx / 2) per 16 points
+    // nx = 4: two tiles of two output rows per 16 points; nx = 5..8: ceil(nx / 3) tiles of up to three rows
+    a.n_ftiles = do_f ? (m.nx >= 5 ? (m.nx + 2) / 3 * tiles : (m.nx == 4 ? 2 * tiles : tiles)) : 0;
     const int grid = a.n_ftiles + (do_h ? tiles : 0);
-    const int nout_tile = m.nx >= 4 ? 2 : (m.nx > m.ny ? m.nx : m.ny);
+    const int nout_tile = m.nx >= 5 ? 3 : (m.nx == 4 ? 2 : (m.nx > m.ny ? m.nx : m.ny));
     const int nin = m.nx + m.nu;
     const size_t lds_bytes = sizeof(float) * (4096 + 4096 * nout_tile + (nin > 8 ? PK_TAIL_EXT2 : (nin > 4 ? PK_TAIL_EXT : PK_TAIL)));
     const int mode = !h2 ? 0 : (nt.recur ? 2 : 1);

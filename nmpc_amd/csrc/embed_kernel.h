@@ -177,7 +177,7 @@ __device__ __forceinline__ void embed_tile(const float* __restrict__ pack, float
 // the set-up launches (target selector, stand-alone calls); the code is identical.
 // MODE: 0 fp32 MFMA path (embed_tile), 1 split-fp16 path (embed_tile_h2), 2 the same with the node recurrence.
 template <int NX, int NU, int NY, bool LOOP, int MODE>
-__global__ __launch_bounds__(EMBED_THREADS, NX >= 7 ? 2 : 3) void embed_kernel(EmbedArgs a, NodeTable nt) {   // (seven and eight states: the nine-input prologue and epilogue spill hundreds of registers at three waves per SIMD)
+__global__ __launch_bounds__(EMBED_THREADS, NX >= 5 ? 2 : 3) void embed_kernel(EmbedArgs a, NodeTable nt) {   // (five to eight states: tiles of three output rows, 68 KB of LDS, two workgroups per CU)
     extern __shared__ __align__(16) float lds[];
     int npts = a.npts;
     if (a.count_dev) npts = min(npts, *a.count_dev * a.group);
@@ -185,17 +185,21 @@ __global__ __launch_bounds__(EMBED_THREADS, NX >= 7 ? 2 : 3) void embed_kernel(E
     unsigned long long c0 = 0, r0 = 0;
     if (a.stamps) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }   // diagnostics only
     if (b < a.n_ftiles) {
-        if constexpr (NX >= 4) {          // tiles of two output rows: tiles [i n/P, (i+1) n/P) compute rows 2 i, 2 i + 1, P = ceil(NX / 2)
-            constexpr int NPAIR = (NX + 1) / 2;
-            const int per = a.n_ftiles / NPAIR, pi = b / per, t = b - pi * per;
+        if constexpr (NX >= 5) {          // tiles of up to three output rows: tiles [i n/P, (i+1) n/P) compute rows 3 i .. 3 i + 2, P = ceil(NX / 3)
+            constexpr int NPART = (NX + 2) / 3;
+            const int per = a.n_ftiles / NPART, pi = b / per, t = b - pi * per;
             if (t * EMBED_TILE >= npts) return;
             if constexpr (MODE != 0) {
-                if (pi == 0) embed_tile_h2<NX, NU, 2, MODE == 2, 0, NX>(a.fpack, lds, a.x, a.u, a.A, a.B, t, npts, a.act, a.group, nt);
-                else if (pi == 1) embed_tile_h2<NX, NU, (NX >= 4 ? 2 : 1), MODE == 2, 2, NX>(a.fpack, lds, a.x, a.u, a.A, a.B, t, npts, a.act, a.group, nt);
-                else if constexpr (NPAIR >= 3) {
-                    if (pi == 2) embed_tile_h2<NX, NU, (NX >= 6 ? 2 : 1), MODE == 2, 4, NX>(a.fpack, lds, a.x, a.u, a.A, a.B, t, npts, a.act, a.group, nt);
-                    else if constexpr (NPAIR >= 4) embed_tile_h2<NX, NU, (NX >= 8 ? 2 : 1), MODE == 2, 6, NX>(a.fpack, lds, a.x, a.u, a.A, a.B, t, npts, a.act, a.group, nt);
-                }
+                if (pi == 0) embed_tile_h2<NX, NU, 3, MODE == 2, 0, NX>(a.fpack, lds, a.x, a.u, a.A, a.B, t, npts, a.act, a.group, nt);
+                else if (pi == 1) embed_tile_h2<NX, NU, (NX >= 6 ? 3 : NX - 3), MODE == 2, 3, NX>(a.fpack, lds, a.x, a.u, a.A, a.B, t, npts, a.act, a.group, nt);
+                else if constexpr (NPART >= 3) embed_tile_h2<NX, NU, NX - 6, MODE == 2, 6, NX>(a.fpack, lds, a.x, a.u, a.A, a.B, t, npts, a.act, a.group, nt);
+            }
+        } else if constexpr (NX == 4) {   // two tiles of two output rows: tiles [0, n/2) compute rows 0, 1, tiles [n/2, n) rows 2, 3
+            const int half = a.n_ftiles >> 1, t = b < half ? b : b - half;
+            if (t * EMBED_TILE >= npts) return;
+            if constexpr (MODE != 0) {
+                if (b < half) embed_tile_h2<NX, NU, 2, MODE == 2, 0, 4>(a.fpack, lds, a.x, a.u, a.A, a.B, t, npts, a.act, a.group, nt);
+                else embed_tile_h2<NX, NU, 2, MODE == 2, 2, 4>(a.fpack, lds, a.x, a.u, a.A, a.B, t, npts, a.act, a.group, nt);
             }
         } else {
             if (b * EMBED_TILE >= npts) return;

@@ -80,7 +80,8 @@ __device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, fl
                   L_REC4 = L_REC1 + (PK_REC4 - PK_REC1), L_RED = 0;
     constexpr bool XTAB = NIN > 8 || NOUT_ALL > 4;      // linear branch / origin Jacobian from the [8][12] tables
     static_assert(4 * EMBED_TILE * NOUT * NIN <= 4096, "reduction buffer must fit in the WF region");
-    static_assert(NIN <= 12 && C0 + NOUT <= NOUT_ALL && NOUT_ALL <= 8 && (C0 >= 4 || C0 + NOUT <= 4), "table sizes");
+    static_assert(NIN <= 12 && C0 + NOUT <= NOUT_ALL && NOUT_ALL <= 8, "table sizes");
+    constexpr bool STRADDLE = C0 < 4 && C0 + NOUT > 4;       // output rows on both sides of the two reverse blocks of the pack
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, hq = lane >> 4;
@@ -95,7 +96,15 @@ __device__ __forceinline__ void embed_tile_h2(const float* __restrict__ pack, fl
         f32x4* dst2 = reinterpret_cast<f32x4*>(lds + L_REC1);
         f32x4 stage[NV], stage2 = {0.f, 0.f, 0.f, 0.f}, stage3 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < NV; ++k) stage[k] = (k < NVF ? srcf : srcr)[tid + k * EMBED_THREADS];
+        for (int k = 0; k < NV; ++k) {
+            if constexpr (STRADDLE) {              // row by row: four vectors per thread and row
+                const int c = C0 + (k - NVF) / (NVR / NOUT);
+                const f32x4* srow = reinterpret_cast<const f32x4*>(pack + (c < 4 ? PK_WR + 4096 * c : PK_WR2 + 4096 * (c - 4))) - (NVF + (c - C0) * (NVR / NOUT)) * EMBED_THREADS;
+                stage[k] = (k < NVF ? srcf : srow)[tid + k * EMBED_THREADS];
+            } else {
+                stage[k] = (k < NVF ? srcf : srcr)[tid + k * EMBED_THREADS];
+            }
+        }
         if (tid < TAIL / 4) stage2 = src2[tid];
         if constexpr (TAIL / 4 > EMBED_THREADS) { if (tid + EMBED_THREADS < TAIL / 4) stage3 = src2[tid + EMBED_THREADS]; }
 #pragma unroll
